@@ -1,0 +1,177 @@
+"""Headline benchmark: Msamples/s of the render step on the 800x800 Cornell box.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one batch: `spp` samples per pixel of
+Scenes::cornell_2 at 800x800 (1024 spp, BASELINE.json configs[1]) rendered by
+the HIP megakernel through the C ABI into a device-resident accumulation
+buffer.  With N > 1 (one process per GPU, launched by torch.distributed.run)
+every rank renders its own `spp` samples per step - disjoint global sample
+numbers, so the ranks' images add up to one (N*spp)-sample image - and the
+buffers are combined on rank 0 with one RCCL reduce per step (weak scaling).
+The scene and camera are resident in HBM before the timed region.
+
+Rank 0 prints one JSON line.  `roofline` prices the render kernel against the
+FP32 vector peak (nothing here is a dense contraction, so there is no MFMA):
+algorithmic flops = segments x (63 per triangle test + 18 per sphere test),
+every surface counted as tested for every segment, divided by the kernel's
+duration from HIP events recorded on the launch stream.  `cpu_baseline` times
+the CPU oracle (a port of the reference's serial loop) on a bounded sample of
+the same workload on this box's host, one thread.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd"))
+
+FP32_VECTOR_PEAK_TFLOPS = 157.3      # MI355X: 256 CU x 128 lanes x 2 (packed) x 2 (fma) x 2.4 GHz
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="cornell_2")
+    ap.add_argument("--size", type=int, nargs=2, default=[800, 800], metavar=("W", "H"))
+    ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per step per GPU")
+    ap.add_argument("--numeric", choices=["exact", "fast"], default="exact")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cpu-spp", type=int, default=12,
+                    help="samples per pixel of the CPU baseline's bounded sample (0 = skip)")
+    return ap.parse_args()
+
+
+def cpu_baseline(scene_name, width, height, spp):
+    """The CPU oracle, one thread, on `spp` samples per pixel of the same scene."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pt_oracle
+    sc = pt_oracle.builtin_scene(scene_name, width, height)
+    pt_oracle.render(sc, 1, threads=1)                      # page in
+    t0 = time.perf_counter()
+    _, cnt = pt_oracle.render(sc, spp, first_sample=0, seed=1, threads=1)
+    dt = time.perf_counter() - t0
+    return {"value": width * height * spp / dt / 1e6, "unit": "Msamples/s", "cores": 1,
+            "kind": "port",
+            "sample": "%s %dx%d, %d spp (%.1f s, %.2f segments/sample)" % (
+                scene_name, width, height, spp, dt, cnt.segments / cnt.samples)}
+
+
+def pmc_traffic():
+    """HBM bytes per render-kernel launch from the committed rocprofv3 PMC summary, if any."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import pt_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run "
+                         "--nproc-per-node %d" % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("no GPU: the render step has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    width, height = args.size
+    mode = pt_amd.MODE_MEGAKERNEL | (pt_amd.NUM_FAST if args.numeric == "fast" else pt_amd.NUM_EXACT)
+    scene = pt_amd.builtin_scene(args.scene, width, height)
+    ctx = pt_amd.Context(local_rank)
+    ctx.load(scene)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    accum = torch.zeros(height, width, 3, dtype=torch.float32, device="cuda")
+
+    def step(i):
+        # global sample numbers: step-major, then rank, so no two (step, rank) overlap
+        first = (i * world + rank) * args.spp
+        ctx.render_into(accum.data_ptr(), args.spp, first, args.seed, mode)
+        if world > 1:
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)   # rank 0 now holds the sum of all images
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    kernel_ms, flops, segments = [], [], []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        if world > 1:
+            accum.zero_()                  # each step reduces one batch
+        step(args.warmup + i)
+        c = ctx.counters()                 # waits for this step's kernels (HIP events)
+        kernel_ms.append(c.kernel_ms)
+        flops.append(c.flops)
+        segments.append(c.segments)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        samples_per_step = width * height * args.spp * world
+        value = samples_per_step * args.steps / elapsed / 1e6
+        avg_ms = sum(kernel_ms) / len(kernel_ms)
+        achieved = sum(flops) / len(flops) / (avg_ms * 1e-3) / 1e12
+        n_surf = len(scene.surfaces)
+        out = {
+            "metric": "Msamples/sec, 800x800 Cornell box (diffuse+mirror+glass)",
+            "value": value,
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "%s %dx%d, %d spp per GPU per step, megakernel, %s arithmetic" % (
+                           args.scene, width, height, args.spp, args.numeric),
+                       "scene": args.scene, "width": width, "height": height, "spp_per_gpu": args.spp,
+                       "layout": "megakernel", "numeric": args.numeric,
+                       "parallelism": "spp-partition x%d + one RCCL reduce per step" % world
+                                      if world > 1 else "single GPU"},
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / FP32_VECTOR_PEAK_TFLOPS,
+                         "traffic": pmc_traffic(),
+                         "kernel": "k_render_mega", "kernel_ms": avg_ms,
+                         "flops_per_launch": sum(flops) / len(flops)},
+            "tests_per_s": sum(segments) / len(segments) * n_surf / (avg_ms * 1e-3),
+            "segments_per_sample": sum(segments) / len(segments) / (width * height * args.spp),
+            "vgprs": int(c.vgprs),
+            "grid_blocks": int(c.grid_blocks),
+        }
+        if world == 1 and args.cpu_spp > 0:
+            out["cpu_baseline"] = cpu_baseline(args.scene, width, height, args.cpu_spp)
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

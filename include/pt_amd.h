@@ -1,0 +1,195 @@
+/*
+ * pt_amd.h -- C ABI of the MI355X-native render step.
+ *
+ * The reference (jvgille/Path-Tracer) has no plugin or FFI interface: its
+ * render step is the free function `void trace_rays(Scene&, BUFFER&)`
+ * (src/main.cpp:114-143), called once per sample-per-pixel pass from
+ * `update()` (src/main.cpp:270).  This header is the flat C boundary a host
+ * binds in its place; each entry point names the reference code it replaces.
+ *
+ * Conventions: every function returns 0 on success and a negative PT_E_* code
+ * on failure; pt_last_error() then describes the failure.  Nothing throws
+ * across this boundary.  One context drives one GPU; calls on one context
+ * must be serialised by the caller; different contexts are independent.
+ * Host pointers are owned by the caller.  The HIP library is the only
+ * implementation: there is no CPU fallback.
+ */
+#ifndef PT_AMD_H
+#define PT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_OK            0
+#define PT_E_INVALID    -1   /* bad argument or call order */
+#define PT_E_HIP        -2   /* a HIP runtime call failed */
+#define PT_E_NOMEM      -3
+#define PT_E_LIMIT      -4   /* size beyond a documented maximum */
+
+/* MaterialType, src/material.hpp:9-11 */
+#define PT_DIFFUSE  0
+#define PT_MIRROR   1
+#define PT_GLASS    2
+/* class Triangle / class Sphere, src/surface.hpp:31,76 */
+#define PT_TRIANGLE 0
+#define PT_SPHERE   1
+
+/* pt_render mode bits */
+#define PT_MODE_MEGAKERNEL 0x0   /* one persistent kernel, whole paths in registers */
+#define PT_MODE_WAVEFRONT  0x1   /* queue-per-bounce kernels, path state in HBM */
+#define PT_NUM_EXACT       0x0   /* no FMA contraction, IEEE divide/sqrt: the parity arithmetic */
+#define PT_NUM_FAST        0x10  /* FMA + hardware rcp/rsq/sin/cos */
+
+/* One Surface, in scene order (Scene::surfaces, src/scene.hpp:18).
+ * Triangle (src/surface.hpp:33-35): a,b,c = v0,v1,v2.
+ * Sphere   (src/surface.hpp:78-79): a = position, b[0] = radius. */
+typedef struct pt_surface {
+    int32_t kind;        /* PT_TRIANGLE | PT_SPHERE */
+    int32_t material;    /* index into the material table */
+    float a[3];
+    float b[3];
+    float c[3];
+} pt_surface;
+
+/* class Material, src/material.hpp:69-76 */
+typedef struct pt_material {
+    int32_t type;        /* PT_DIFFUSE | PT_MIRROR | PT_GLASS */
+    float color[3];
+    float emittance[3];
+} pt_material;
+
+/* class Camera (src/camera.hpp:12-16) as trace_rays reads it, plus the
+ * Scene's depth-of-field fields (src/scene.hpp:20-22) and the image size,
+ * compile-time in the reference (src/constants.hpp:6-7), runtime here.
+ * rot is the GLM column-major rotation matrix: rot[3*c + r] = m[c][r]. */
+typedef struct pt_camera {
+    float pos[3];
+    float rot[9];
+    float focal;               /* focal length in pixels */
+    int32_t width;
+    int32_t height;
+    int32_t dof_on;
+    float dof_focal_length;
+    float dof_aperture;
+} pt_camera;
+
+typedef struct pt_counters {
+    uint64_t samples;          /* paths traced by the last pt_render */
+    uint64_t segments;         /* closest-hit queries (src/main.cpp:85) in the last pt_render */
+    uint64_t tests;            /* segments x surfaces */
+    double kernel_ms;          /* device time of the last pt_render's render kernel (HIP events) */
+    double total_ms;           /* the same including the partial-sum reduction */
+    double flops;              /* algorithmic flops: segments x (63 n_tri + 18 n_sph) */
+    uint32_t vgprs;            /* registers per lane of the render kernel */
+    uint32_t grid_blocks;      /* workgroups launched */
+} pt_counters;
+
+typedef struct pt_ctx pt_ctx;
+
+#define PT_MAX_DEPTH 1024      /* safety cap on path length; the reference has none */
+
+/* Library-wide: message for a failed pt_create (no context exists yet). */
+const char *pt_global_error(void);
+
+/* Lifetime.  device = HIP device ordinal.  Replaces nothing in the reference
+ * (it has no device); owns the device copies of the scene and the buffers. */
+int  pt_create(int device, pt_ctx **out);
+void pt_destroy(pt_ctx *ctx);
+const char *pt_last_error(pt_ctx *ctx);
+
+/* Stream all later work is enqueued on (a hipStream_t; NULL = default). */
+int pt_set_stream(pt_ctx *ctx, void *hip_stream);
+
+/* Uploads Scene::surfaces and Scene::BG_COLOR (src/scene.hpp:15-18).  Derived
+ * values are computed here in the reference's arithmetic: Triangle::normal =
+ * normalize(cross(v2-v0, v1-v0)) (src/surface.hpp:40), Sphere::radius2
+ * (src/surface.hpp:83). */
+int pt_set_scene(pt_ctx *ctx, const pt_surface *surfaces, int32_t n_surfaces,
+                 const pt_material *materials, int32_t n_materials, const float bg[3]);
+
+/* Uploads the camera and DOF state; (re)allocates the accumulation buffer
+ * when the image size changes and clears it, as src/main.cpp:262-269 does
+ * when the camera moved. */
+int pt_set_camera(pt_ctx *ctx, const pt_camera *cam);
+
+/* Zeroes the accumulation buffer and the sample counter
+ * (src/main.cpp:262-269: TOTAL_SAMPLES = 0; buffer = 0). */
+int pt_clear(pt_ctx *ctx);
+
+/* trace_rays (src/main.cpp:114-143) run spp times: adds spp samples per pixel
+ * to the context's accumulation buffer and spp to its sample counter
+ * (TOTAL_SAMPLES, src/main.cpp:142).  Samples are numbered first_sample ..
+ * first_sample+spp-1; the random stream of a path depends only on (seed,
+ * pixel, sample number), so disjoint sample ranges rendered on different GPUs
+ * add up to the same image as one range rendered on one GPU. */
+int pt_render(pt_ctx *ctx, uint32_t spp, uint32_t first_sample, uint64_t seed, int mode);
+
+/* The same, adding into a caller-owned DEVICE buffer of height*width*3 floats
+ * (row-major, pixel (u,v) at 3*(v*width+u)); the context's own buffer and
+ * counter are untouched.  For hosts that hold the image in their own device
+ * memory (for instance to reduce it across GPUs). */
+int pt_render_into(pt_ctx *ctx, float *accum_device, uint32_t spp, uint32_t first_sample,
+                   uint64_t seed, int mode);
+
+/* Copies the accumulation buffer (BUFFER, src/main.cpp:31, as running sums)
+ * to host memory, height*width*3 floats row-major, and the sample counter.
+ * Either pointer may be NULL. */
+int pt_read_accum(pt_ctx *ctx, float *rgb_sum_host, uint64_t *total_samples);
+
+/* Replaces the accumulation buffer and the sample counter with caller data
+ * (height*width*3 floats, row-major): resumes an image read back earlier with
+ * pt_read_accum, or hands a host-side BUFFER to pt_tonemap_rgb8. */
+int pt_write_accum(pt_ctx *ctx, const float *rgb_sum_host, uint64_t total_samples);
+
+/* draw()'s per-pixel conversion (src/main.cpp:146-162) with PutPixelSDL's
+ * truncation (src/sdl_helpers.hpp:68-70): rgb8 = uint8(to_ldr(sum/N)).
+ * out_host: height*width*3 bytes. */
+int pt_tonemap_rgb8(pt_ctx *ctx, uint8_t *out_host);
+
+/* Parity entry points (EXACT arithmetic).  Host pointers. */
+
+/* get_ray_direction_by_pixel (src/main.cpp:50-54) on integer pixel corners,
+ * then closest_intersection (src/main.cpp:56-67).  surf_idx[v*W+u] = index in
+ * scene order or -1; distance = Intersection::distance (0 on a miss). */
+int pt_primary_hits(pt_ctx *ctx, int32_t *surf_idx, float *distance);
+
+/* closest_intersection (src/main.cpp:56-67) with Triangle::intersects
+ * (src/surface.hpp:47-73) and Sphere::intersects (src/surface.hpp:91-112) on
+ * caller-supplied rays.  origin, dir, point: n x 3 floats. */
+int pt_intersect_rays(pt_ctx *ctx, const float *origin, const float *dir, int64_t n,
+                      int32_t *surf_idx, float *distance, float *point);
+
+/* The ray set-up of trace_rays (src/main.cpp:120-136) with forced random
+ * numbers.  px: n x 2 (u,v); xi: n x 4 = jitter u, jitter v, lens radius
+ * draw, lens angle draw.  origin, dir: n x 3.  numeric = PT_NUM_EXACT|FAST. */
+int pt_camera_rays(pt_ctx *ctx, const int32_t *px, const float *xi, int64_t n,
+                   float *origin, float *dir, int numeric);
+
+/* Material::sample_pdf and Material::brdf (src/material.hpp:78-96) with
+ * forced random numbers.  type: n; color, normal, incident: n x 3; xi: n x 2
+ * (diffuse uses both, glass the first).  numeric = PT_NUM_EXACT|FAST. */
+int pt_eval_bsdf(pt_ctx *ctx, const int32_t *type, const float *color, const float *normal,
+                 const float *incident, const float *xi, int64_t n,
+                 float *out_dir, float *out_brdf, int numeric);
+
+/* Material::brdf (src/material.hpp:89-96) alone, for a caller-supplied
+ * outgoing direction.  type: n; color, normal, reflected, out_brdf: n x 3. */
+int pt_eval_brdf(pt_ctx *ctx, const int32_t *type, const float *color, const float *normal,
+                 const float *reflected, int64_t n, float *out_brdf);
+
+/* The uniform (0,1) variate that draw number `draw` of path (pixel, sample)
+ * uses: the counter-based replacement for random_real (src/main.cpp:42-44).
+ * Evaluated on the device.  out: n floats; pixel, sample, draw: n each. */
+int pt_rng_uniform(pt_ctx *ctx, uint64_t seed, const uint32_t *pixel, const uint32_t *sample,
+                   const uint32_t *draw, int64_t n, float *out);
+
+/* Statistics of the last pt_render / pt_render_into (waits for it). */
+int pt_get_counters(pt_ctx *ctx, pt_counters *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_AMD_H */

@@ -1,0 +1,140 @@
+/*
+ * pt_oracle.h -- CPU restatement of the reference path tracer's render step.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the shipped
+ * product: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this library, and only as the checker.
+ *
+ * PARITY UNPINNED: the reference (jvgille/Path-Tracer) ships no tests, golden
+ * vectors or fixtures for this path, and it cannot be built in this image (it
+ * needs GLM and SDL 1.2, neither of which is present).  Every function below
+ * restates the reference's algorithm from its source text, citing file:line,
+ * with GLM's published scalar formulas for dot/cross/length/normalize/
+ * determinant/mat3 products.
+ *
+ * Plain C, fp32 arithmetic with no fused multiply-add (build with
+ * -ffp-contract=off and no -march: the reference's own x86-64 build has no
+ * FMA either, CMakeLists.txt:10).
+ */
+#ifndef PT_ORACLE_H
+#define PT_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* material.hpp:9-11 */
+enum { ORC_DIFFUSE = 0, ORC_MIRROR = 1, ORC_GLASS = 2 };
+/* surface.hpp:31 (Triangle), surface.hpp:76 (Sphere) */
+enum { ORC_TRIANGLE = 0, ORC_SPHERE = 1 };
+
+/* One Surface in scene order (scene.hpp:18).  Triangle: a,b,c = v0,v1,v2
+ * (surface.hpp:33-35).  Sphere: a = position, b[0] = radius (surface.hpp:78-79). */
+typedef struct orc_surface {
+    int32_t kind;
+    int32_t material;          /* index into the material table */
+    float a[3];
+    float b[3];
+    float c[3];
+} orc_surface;
+
+/* material.hpp:69-76 */
+typedef struct orc_material {
+    int32_t type;
+    float color[3];
+    float emittance[3];
+} orc_material;
+
+/* camera.hpp:12-16 plus the Scene's DOF fields (scene.hpp:20-22) and the
+ * compile-time SCREEN_WIDTH/SCREEN_HEIGHT (constants.hpp:6-7) made runtime.
+ * rot is GLM column-major: rot[3*c + r] = m[c][r]. */
+typedef struct orc_camera {
+    float pos[3];
+    float rot[9];
+    float focal;
+    int32_t width;
+    int32_t height;
+    int32_t dof_on;
+    float dof_focal_length;
+    float dof_aperture;
+} orc_camera;
+
+typedef struct orc_scene {
+    int32_t n_surfaces;
+    int32_t n_materials;
+    const orc_surface *surfaces;
+    const orc_material *materials;
+    float bg[3];               /* Scene::BG_COLOR, scene.hpp:17 */
+} orc_scene;
+
+typedef struct orc_counters {
+    uint64_t samples;          /* primary paths traced */
+    uint64_t segments;         /* closest_intersection calls (main.cpp:85) */
+    uint64_t max_depth;        /* longest path seen, in segments */
+} orc_counters;
+
+#define ORC_MAX_BUILTIN_SURFACES 16
+#define ORC_MAX_DEPTH 1024     /* safety cap; the reference has none (main.cpp:84) */
+
+/* camera.hpp:20-27,34-39: builds rot from (rot_x, rot_y); add_offset != 0
+ * adds OFFSET = (2e-5, 1e-5) as the 3-argument constructor does. */
+void orc_camera_init(orc_camera *cam, const float pos[3], float rot_x, float rot_y,
+                     float focal, int add_offset, int width, int height);
+
+/* scene.hpp:32-203.  name in {dof_demo,test,orange_plane,red_corner,sunrise,
+ * cornell_2,cornell}.  Arrays must hold ORC_MAX_BUILTIN_SURFACES entries.
+ * Every surface gets a material of its own (surface.hpp:22 copies by value).
+ * Returns 0, or -1 for an unknown name. */
+int orc_builtin_scene(const char *name, int width, int height,
+                      orc_surface *surfaces, orc_material *materials,
+                      int32_t *n_surfaces, float bg[3], orc_camera *cam);
+
+/* main.cpp:50-54 on integer pixel corners (no jitter), then main.cpp:56-67.
+ * idx[y*W+x] = surface index or -1; dist = Intersection::distance (0 on miss). */
+void orc_primary_hits(const orc_scene *scene, const orc_camera *cam,
+                      int32_t *idx, float *dist);
+
+/* main.cpp:56-67 on caller-supplied rays (o,d: n x 3).  point: n x 3. */
+void orc_intersect_rays(const orc_scene *scene, const float *o, const float *d,
+                        int64_t n, int32_t *idx, float *dist, float *point);
+
+/* main.cpp:120-136 with forced random numbers.  px: n x 2 int32 (u,v);
+ * xi: n x 4 = jitter_u, jitter_v, lens radius draw, lens angle draw (the last
+ * two unused when DOF is off).  Outputs n x 3 each. */
+void orc_camera_rays(const orc_camera *cam, const int32_t *px, const float *xi,
+                     int64_t n, float *origin, float *dir);
+
+/* material.hpp:78-96 with forced random numbers.  type: n; color, normal,
+ * incident: n x 3; xi: n x 2 (diffuse uses both, glass the first).
+ * out_dir = sample_pdf(normal, incident); out_brdf = brdf(normal, out_dir). */
+void orc_eval_bsdf(const int32_t *type, const float *color, const float *normal,
+                   const float *incident, const float *xi, int64_t n,
+                   float *out_dir, float *out_brdf);
+
+/* The counter-based generator the build uses in place of libc rand()
+ * (main.cpp:42-44): uniform in (0,1), 23 random bits, never 0 or 1. */
+float orc_rng_uniform(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t draw);
+
+/* main.cpp:114-143 repeated spp times with the counter-based generator keyed
+ * on (seed, pixel = y*W+x, first_sample + s, draw index).  accum: H x W x 3
+ * running sums, row-major, ADDED to.  Pixels are split over `threads` OpenMP
+ * threads (1 = serial, as the reference runs).  counters may be NULL. */
+void orc_render(const orc_scene *scene, const orc_camera *cam, uint32_t spp,
+                uint32_t first_sample, uint64_t seed, int threads,
+                float *accum, orc_counters *counters);
+
+/* The same render step drawing from libc rand() exactly as main.cpp:42-44
+ * does (xi in [0,1], shared global state, serial).  srand(seed) first. */
+void orc_render_libc_rand(const orc_scene *scene, const orc_camera *cam, uint32_t spp,
+                          unsigned seed, float *accum, orc_counters *counters);
+
+/* main.cpp:146-148 followed by the Uint8 truncation of sdl_helpers.hpp:68-70.
+ * sum: n x 3 running sums; rgb: n x 3 bytes. */
+void orc_tonemap(const float *sum, int64_t n, uint32_t total_samples, uint8_t *rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_ORACLE_H */

@@ -1,0 +1,645 @@
+// C ABI of the MI355X-native render step (declared in include/pt_amd.h):
+// context, scene flattening, launches.  Build with
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
+#include "../../include/pt_amd.h"
+#include "pt_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace ptd;
+
+namespace {
+
+thread_local std::string g_error;
+
+struct HostV3 { float x, y, z; };
+inline HostV3 hsub(HostV3 a, HostV3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline float hdot(HostV3 a, HostV3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline HostV3 hcross(HostV3 x, HostV3 y)
+{
+    return {x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y};
+}
+inline HostV3 hnormalize(HostV3 a)
+{
+    const float inv = 1.0f / std::sqrt(hdot(a, a));
+    return {a.x * inv, a.y * inv, a.z * inv};
+}
+
+uint32_t host_pcg(uint32_t v)
+{
+    uint32_t s = v * 747796405u + 2891336453u;
+    uint32_t w = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
+    return (w >> 22) ^ w;
+}
+uint32_t host_seed_mix(uint64_t seed)
+{
+    return host_pcg(host_pcg((uint32_t)seed) ^ (uint32_t)(seed >> 32));
+}
+
+}  // namespace
+
+struct pt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+
+    bool have_scene = false, have_camera = false;
+    int n_surfaces = 0, n_tri = 0, n_sph = 0;
+    float bg[3] = {0, 0, 0};
+    Camera cam{};
+    float *d_geom = nullptr, *d_shade = nullptr;
+
+    float *d_accum = nullptr;        // height*width*3 running sums
+    size_t accum_floats = 0;
+    uint64_t total_samples = 0;
+
+    float *d_slabs = nullptr;        // partial sums of the work items
+    size_t slab_floats = 0;
+    uint32_t *d_queue = nullptr;     // [0] work counter; 8 bytes further: the segment counter
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+
+    int num_cus = 0;
+    pt_counters last{};
+    bool last_valid = false, last_pending = false;
+};
+
+namespace {
+
+int fail(pt_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->error = buf;
+    g_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                              \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return fail(ctx, PT_E_HIP, "%s: %s (%s:%d)", #call, hipGetErrorString(e_),  \
+                        __FILE__, __LINE__);                                            \
+    } while (0)
+
+int use_device(pt_ctx *ctx)
+{
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return PT_OK;
+}
+
+template <typename T>
+int dev_alloc(pt_ctx *ctx, T **p, size_t count)
+{
+    hipError_t e = hipMalloc((void **)p, count * sizeof(T));
+    if (e != hipSuccess) {
+        *p = nullptr;
+        return fail(ctx, PT_E_NOMEM, "hipMalloc of %zu bytes failed: %s", count * sizeof(T),
+                    hipGetErrorString(e));
+    }
+    return PT_OK;
+}
+
+// Scratch device buffer that lives for one call.
+template <typename T>
+struct Scratch {
+    T *p = nullptr;
+    ~Scratch() { if (p) (void)hipFree(p); }
+};
+
+template <typename T>
+int upload(pt_ctx *ctx, Scratch<T> &s, const T *host, size_t count)
+{
+    int rc = dev_alloc(ctx, &s.p, std::max<size_t>(count, 1));
+    if (rc) return rc;
+    if (count) HIP_TRY(ctx, hipMemcpyAsync(s.p, host, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return PT_OK;
+}
+
+unsigned blocks_for(long long n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+
+int check_ready(pt_ctx *ctx, bool need_camera)
+{
+    if (!ctx) return fail(nullptr, PT_E_INVALID, "null context");
+    if (!ctx->have_scene) return fail(ctx, PT_E_INVALID, "pt_set_scene has not been called");
+    if (need_camera && !ctx->have_camera) return fail(ctx, PT_E_INVALID, "pt_set_camera has not been called");
+    return use_device(ctx);
+}
+
+template <bool FAST>
+int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample, uint64_t seed)
+{
+    const uint32_t n_pixels = (uint32_t)ctx->cam.width * (uint32_t)ctx->cam.height;
+    const size_t lds_bytes = (size_t)ctx->n_surfaces * SHADE_STRIDE * sizeof(float);
+
+    int blocks_per_cu = 0;
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_render_mega<FAST>, BLOCK, lds_bytes));
+    if (blocks_per_cu < 1) return fail(ctx, PT_E_HIP, "render kernel does not fit on a compute unit");
+    const uint32_t grid = (uint32_t)blocks_per_cu * (uint32_t)ctx->num_cus;
+    const uint64_t lanes = (uint64_t)grid * BLOCK;
+
+    // Work items: enough per lane (about 16) that the last ones to finish cost
+    // little, but no more chunks than samples.
+    uint64_t want_chunks = (16 * lanes + n_pixels - 1) / n_pixels;
+    uint32_t n_chunks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want_chunks, 1), spp);
+    const uint32_t chunk_len = (spp + n_chunks - 1) / n_chunks;
+    n_chunks = (spp + chunk_len - 1) / chunk_len;
+    const uint64_t n_items64 = (uint64_t)n_pixels * n_chunks;
+    if (n_items64 >= 0xF0000000ull)
+        return fail(ctx, PT_E_LIMIT, "%llu work items exceed the 32-bit queue", (unsigned long long)n_items64);
+
+    const size_t need = (size_t)n_items64 * 3;
+    if (need > ctx->slab_floats) {
+        if (ctx->d_slabs) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_slabs); }
+        ctx->d_slabs = nullptr;
+        ctx->slab_floats = 0;
+        int rc = dev_alloc(ctx, &ctx->d_slabs, need);
+        if (rc) return rc;
+        ctx->slab_floats = need;
+    }
+
+    RenderParams P{};
+    P.cam = ctx->cam;
+    P.geom = ctx->d_geom;
+    P.shade = ctx->d_shade;
+    P.n_surfaces = ctx->n_surfaces;
+    memcpy(P.bg, ctx->bg, sizeof P.bg);
+    P.seed_mix = host_seed_mix(seed);
+    P.first_sample = first_sample;
+    P.spp = spp;
+    P.chunk_len = chunk_len;
+    P.n_pixels = n_pixels;
+    P.n_items = (uint32_t)n_items64;
+    P.slabs = ctx->d_slabs;
+    P.queue_head = ctx->d_queue;
+    P.stats = reinterpret_cast<unsigned long long *>(ctx->d_queue + 2);
+
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 16, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    hipLaunchKernelGGL(k_render_mega<FAST>, dim3(grid), dim3(BLOCK), lds_bytes, ctx->stream, P);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    const size_t n = (size_t)n_pixels * 3;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks_for((long long)n)), dim3(BLOCK), 0, ctx->stream,
+                       ctx->d_slabs, n_chunks, n, accum);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+
+    hipFuncAttributes attr{};
+    HIP_TRY(ctx, hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k_render_mega<FAST>)));
+    ctx->last = pt_counters{};
+    ctx->last.samples = (uint64_t)n_pixels * spp;
+    ctx->last.vgprs = (uint32_t)attr.numRegs;
+    ctx->last.grid_blocks = grid;
+    ctx->last_valid = true;
+    ctx->last_pending = true;
+    return PT_OK;
+}
+
+int render_dispatch(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample, uint64_t seed, int mode)
+{
+    if (spp == 0) return fail(ctx, PT_E_INVALID, "spp must be positive");
+    if ((uint64_t)first_sample + spp > 0xFFFFFFFFull)
+        return fail(ctx, PT_E_LIMIT, "sample numbers must fit in 32 bits");
+    if (mode & ~(PT_MODE_WAVEFRONT | PT_NUM_FAST)) return fail(ctx, PT_E_INVALID, "unknown mode bits 0x%x", mode);
+    if (mode & PT_MODE_WAVEFRONT) return fail(ctx, PT_E_INVALID, "the wavefront layout is not built");
+    if (mode & PT_NUM_FAST) return launch_render<true>(ctx, accum, spp, first_sample, seed);
+    return launch_render<false>(ctx, accum, spp, first_sample, seed);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pt_global_error(void) { return g_error.c_str(); }
+
+int pt_create(int device, pt_ctx **out)
+{
+    if (!out) return fail(nullptr, PT_E_INVALID, "out is null");
+    *out = nullptr;
+    int count = 0;
+    HIP_TRY(nullptr, hipGetDeviceCount(&count));
+    if (device < 0 || device >= count)
+        return fail(nullptr, PT_E_INVALID, "device %d out of range (%d visible)", device, count);
+    pt_ctx *ctx = new (std::nothrow) pt_ctx;
+    if (!ctx) return fail(nullptr, PT_E_NOMEM, "out of host memory");
+    ctx->device = device;
+    hipError_t e = hipSetDevice(device);
+    hipDeviceProp_t prop{};
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        delete ctx;
+        return fail(nullptr, PT_E_HIP, "device %d is %s; this library holds gfx950 code only", device, prop.gcnArchName);
+    }
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_queue, 16);
+    for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipEventCreate(&ctx->ev[i]);
+    if (e != hipSuccess) {
+        int rc = fail(nullptr, PT_E_HIP, "pt_create on device %d: %s", device, hipGetErrorString(e));
+        pt_destroy(ctx);
+        return rc;
+    }
+    ctx->num_cus = prop.multiProcessorCount;
+    *out = ctx;
+    return PT_OK;
+}
+
+void pt_destroy(pt_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (hipEvent_t ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+    if (ctx->d_geom) (void)hipFree(ctx->d_geom);
+    if (ctx->d_shade) (void)hipFree(ctx->d_shade);
+    if (ctx->d_accum) (void)hipFree(ctx->d_accum);
+    if (ctx->d_slabs) (void)hipFree(ctx->d_slabs);
+    if (ctx->d_queue) (void)hipFree(ctx->d_queue);
+    delete ctx;
+}
+
+const char *pt_last_error(pt_ctx *ctx) { return ctx ? ctx->error.c_str() : g_error.c_str(); }
+
+int pt_set_stream(pt_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return fail(nullptr, PT_E_INVALID, "null context");
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    return PT_OK;
+}
+
+int pt_set_scene(pt_ctx *ctx, const pt_surface *surfaces, int32_t n_surfaces,
+                 const pt_material *materials, int32_t n_materials, const float bg[3])
+{
+    if (!ctx) return fail(nullptr, PT_E_INVALID, "null context");
+    if (n_surfaces < 0 || n_materials < 0 || (n_surfaces > 0 && (!surfaces || !materials)) || !bg)
+        return fail(ctx, PT_E_INVALID, "bad scene arguments");
+    const size_t lds_limit = 64 * 1024 / (SHADE_STRIDE * sizeof(float));
+    if ((size_t)n_surfaces > lds_limit)
+        return fail(ctx, PT_E_LIMIT, "%d surfaces exceed the %zu this build keeps in LDS", n_surfaces, lds_limit);
+    int rc = use_device(ctx);
+    if (rc) return rc;
+
+    std::vector<float> geom((size_t)std::max(n_surfaces, 1) * GEOM_STRIDE, 0.0f);
+    std::vector<float> shade((size_t)std::max(n_surfaces, 1) * SHADE_STRIDE, 0.0f);
+    int n_tri = 0, n_sph = 0;
+    for (int i = 0; i < n_surfaces; i++) {
+        const pt_surface &s = surfaces[i];
+        if (s.material < 0 || s.material >= n_materials)
+            return fail(ctx, PT_E_INVALID, "surface %d names material %d of %d", i, s.material, n_materials);
+        const pt_material &m = materials[s.material];
+        if (m.type < PT_DIFFUSE || m.type > PT_GLASS)
+            return fail(ctx, PT_E_INVALID, "material %d has unknown type %d", s.material, m.type);
+        float *g = &geom[(size_t)i * GEOM_STRIDE];
+        float *sh = &shade[(size_t)i * SHADE_STRIDE];
+        const int32_t kind = s.kind;
+        memcpy(g + 3, &kind, 4);
+        if (kind == PT_TRIANGLE) {
+            const HostV3 v0{s.a[0], s.a[1], s.a[2]}, v1{s.b[0], s.b[1], s.b[2]}, v2{s.c[0], s.c[1], s.c[2]};
+            const HostV3 e1 = hsub(v1, v0), e2 = hsub(v2, v0);          // surface.hpp:48-49
+            const HostV3 nrm = hnormalize(hcross(hsub(v2, v0), hsub(v1, v0)));  // surface.hpp:40
+            g[0] = v0.x; g[1] = v0.y; g[2] = v0.z;
+            g[4] = e1.x; g[5] = e1.y; g[6] = e1.z;
+            g[7] = e1.y * e2.z - e2.y * e1.z;
+            g[8] = e2.x; g[9] = e2.y; g[10] = e2.z;
+            sh[8] = nrm.x; sh[9] = nrm.y; sh[10] = nrm.z;
+            n_tri++;
+        } else if (kind == PT_SPHERE) {
+            g[0] = s.a[0]; g[1] = s.a[1]; g[2] = s.a[2];
+            g[4] = s.b[0] * s.b[0];                                      // surface.hpp:83
+            sh[8] = s.a[0]; sh[9] = s.a[1]; sh[10] = s.a[2];
+            n_sph++;
+        } else {
+            return fail(ctx, PT_E_INVALID, "surface %d has unknown kind %d", i, kind);
+        }
+        const int32_t flags = m.type | (kind << 8);
+        memcpy(sh + 0, m.color, 12);
+        memcpy(sh + 3, &flags, 4);
+        memcpy(sh + 4, m.emittance, 12);
+    }
+
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_geom) (void)hipFree(ctx->d_geom);
+    if (ctx->d_shade) (void)hipFree(ctx->d_shade);
+    ctx->d_geom = ctx->d_shade = nullptr;
+    ctx->have_scene = false;
+    if ((rc = dev_alloc(ctx, &ctx->d_geom, geom.size()))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_shade, shade.size()))) return rc;
+    HIP_TRY(ctx, hipMemcpy(ctx->d_geom, geom.data(), geom.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_shade, shade.data(), shade.size() * sizeof(float), hipMemcpyHostToDevice));
+    ctx->n_surfaces = n_surfaces;
+    ctx->n_tri = n_tri;
+    ctx->n_sph = n_sph;
+    memcpy(ctx->bg, bg, sizeof ctx->bg);
+    ctx->have_scene = true;
+    return PT_OK;
+}
+
+int pt_set_camera(pt_ctx *ctx, const pt_camera *cam)
+{
+    if (!ctx) return fail(nullptr, PT_E_INVALID, "null context");
+    if (!cam) return fail(ctx, PT_E_INVALID, "camera is null");
+    if (cam->width < 1 || cam->height < 1 || (int64_t)cam->width * cam->height > (1ll << 28))
+        return fail(ctx, PT_E_LIMIT, "image size %d x %d out of range", cam->width, cam->height);
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    const size_t floats = (size_t)cam->width * cam->height * 3;
+    if (floats != ctx->accum_floats) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_accum) (void)hipFree(ctx->d_accum);
+        ctx->d_accum = nullptr;
+        ctx->accum_floats = 0;
+        if ((rc = dev_alloc(ctx, &ctx->d_accum, floats))) return rc;
+        ctx->accum_floats = floats;
+    }
+    memcpy(ctx->cam.pos, cam->pos, sizeof cam->pos);
+    memcpy(ctx->cam.rot, cam->rot, sizeof cam->rot);
+    ctx->cam.focal = cam->focal;
+    ctx->cam.width = cam->width;
+    ctx->cam.height = cam->height;
+    ctx->cam.dof_on = cam->dof_on != 0;
+    ctx->cam.dof_focal_length = cam->dof_focal_length;
+    ctx->cam.dof_aperture = cam->dof_aperture;
+    ctx->have_camera = true;
+    return pt_clear(ctx);
+}
+
+int pt_clear(pt_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, PT_E_INVALID, "null context");
+    if (!ctx->have_camera) return fail(ctx, PT_E_INVALID, "pt_set_camera has not been called");
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_accum, 0, ctx->accum_floats * sizeof(float), ctx->stream));
+    ctx->total_samples = 0;
+    return PT_OK;
+}
+
+int pt_render(pt_ctx *ctx, uint32_t spp, uint32_t first_sample, uint64_t seed, int mode)
+{
+    int rc = check_ready(ctx, true);
+    if (rc) return rc;
+    rc = render_dispatch(ctx, ctx->d_accum, spp, first_sample, seed, mode);
+    if (rc == PT_OK) ctx->total_samples += spp;
+    return rc;
+}
+
+int pt_render_into(pt_ctx *ctx, float *accum_device, uint32_t spp, uint32_t first_sample,
+                   uint64_t seed, int mode)
+{
+    int rc = check_ready(ctx, true);
+    if (rc) return rc;
+    if (!accum_device) return fail(ctx, PT_E_INVALID, "accum_device is null");
+    hipPointerAttribute_t pa{};
+    if (hipPointerGetAttributes(&pa, accum_device) != hipSuccess || pa.type != hipMemoryTypeDevice) {
+        (void)hipGetLastError();
+        return fail(ctx, PT_E_INVALID, "accum_device is not device memory");
+    }
+    if (pa.device != ctx->device)
+        return fail(ctx, PT_E_INVALID, "accum_device lives on device %d, the context on %d", pa.device, ctx->device);
+    return render_dispatch(ctx, accum_device, spp, first_sample, seed, mode);
+}
+
+int pt_read_accum(pt_ctx *ctx, float *rgb_sum_host, uint64_t *total_samples)
+{
+    if (!ctx) return fail(nullptr, PT_E_INVALID, "null context");
+    if (!ctx->have_camera) return fail(ctx, PT_E_INVALID, "pt_set_camera has not been called");
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if (rgb_sum_host) {
+        HIP_TRY(ctx, hipMemcpyAsync(rgb_sum_host, ctx->d_accum, ctx->accum_floats * sizeof(float),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (total_samples) *total_samples = ctx->total_samples;
+    return PT_OK;
+}
+
+int pt_write_accum(pt_ctx *ctx, const float *rgb_sum_host, uint64_t total_samples)
+{
+    if (!ctx) return fail(nullptr, PT_E_INVALID, "null context");
+    if (!ctx->have_camera) return fail(ctx, PT_E_INVALID, "pt_set_camera has not been called");
+    if (!rgb_sum_host) return fail(ctx, PT_E_INVALID, "rgb_sum_host is null");
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_accum, rgb_sum_host, ctx->accum_floats * sizeof(float),
+                                hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->total_samples = total_samples;
+    return PT_OK;
+}
+
+int pt_tonemap_rgb8(pt_ctx *ctx, uint8_t *out_host)
+{
+    if (!ctx) return fail(nullptr, PT_E_INVALID, "null context");
+    if (!ctx->have_camera || !out_host) return fail(ctx, PT_E_INVALID, "no camera or null output");
+    if (ctx->total_samples == 0) return fail(ctx, PT_E_INVALID, "nothing rendered yet");
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    Scratch<uint8_t> d_out;
+    if ((rc = dev_alloc(ctx, &d_out.p, ctx->accum_floats))) return rc;
+    hipLaunchKernelGGL(k_tonemap, dim3(blocks_for((long long)ctx->accum_floats)), dim3(BLOCK), 0, ctx->stream,
+                       ctx->d_accum, ctx->accum_floats, (float)ctx->total_samples, d_out.p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out_host, d_out.p, ctx->accum_floats, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_primary_hits(pt_ctx *ctx, int32_t *surf_idx, float *distance)
+{
+    int rc = check_ready(ctx, true);
+    if (rc) return rc;
+    if (!surf_idx || !distance) return fail(ctx, PT_E_INVALID, "null output");
+    const long long n = (long long)ctx->cam.width * ctx->cam.height;
+    Scratch<int32_t> d_idx;
+    Scratch<float> d_dist;
+    if ((rc = dev_alloc(ctx, &d_idx.p, (size_t)n))) return rc;
+    if ((rc = dev_alloc(ctx, &d_dist.p, (size_t)n))) return rc;
+    hipLaunchKernelGGL(k_primary_hits<false>, dim3(blocks_for(n)), dim3(BLOCK), 0, ctx->stream,
+                       ctx->cam, ctx->d_geom, ctx->n_surfaces, d_idx.p, d_dist.p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(surf_idx, d_idx.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(distance, d_dist.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_intersect_rays(pt_ctx *ctx, const float *origin, const float *dir, int64_t n,
+                      int32_t *surf_idx, float *distance, float *point)
+{
+    int rc = check_ready(ctx, false);
+    if (rc) return rc;
+    if (n < 0 || n > (1ll << 31)) return fail(ctx, PT_E_LIMIT, "ray count %lld out of range", (long long)n);
+    if (n == 0) return PT_OK;
+    if (!origin || !dir || !surf_idx || !distance || !point) return fail(ctx, PT_E_INVALID, "null argument");
+    Scratch<float> d_o, d_d, d_dist, d_pt;
+    Scratch<int32_t> d_idx;
+    if ((rc = upload(ctx, d_o, origin, (size_t)n * 3))) return rc;
+    if ((rc = upload(ctx, d_d, dir, (size_t)n * 3))) return rc;
+    if ((rc = dev_alloc(ctx, &d_idx.p, (size_t)n))) return rc;
+    if ((rc = dev_alloc(ctx, &d_dist.p, (size_t)n))) return rc;
+    if ((rc = dev_alloc(ctx, &d_pt.p, (size_t)n * 3))) return rc;
+    hipLaunchKernelGGL(k_intersect_rays<false>, dim3(blocks_for(n)), dim3(BLOCK), 0, ctx->stream,
+                       ctx->d_geom, ctx->n_surfaces, d_o.p, d_d.p, (long long)n, d_idx.p, d_dist.p, d_pt.p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(surf_idx, d_idx.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(distance, d_dist.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(point, d_pt.p, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_camera_rays(pt_ctx *ctx, const int32_t *px, const float *xi, int64_t n,
+                   float *origin, float *dir, int numeric)
+{
+    if (!ctx) return fail(nullptr, PT_E_INVALID, "null context");
+    if (!ctx->have_camera) return fail(ctx, PT_E_INVALID, "pt_set_camera has not been called");
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if (n < 0 || n > (1ll << 31)) return fail(ctx, PT_E_LIMIT, "ray count %lld out of range", (long long)n);
+    if (n == 0) return PT_OK;
+    if (!px || !xi || !origin || !dir) return fail(ctx, PT_E_INVALID, "null argument");
+    Scratch<int32_t> d_px;
+    Scratch<float> d_xi, d_o, d_d;
+    if ((rc = upload(ctx, d_px, px, (size_t)n * 2))) return rc;
+    if ((rc = upload(ctx, d_xi, xi, (size_t)n * 4))) return rc;
+    if ((rc = dev_alloc(ctx, &d_o.p, (size_t)n * 3))) return rc;
+    if ((rc = dev_alloc(ctx, &d_d.p, (size_t)n * 3))) return rc;
+    if (numeric & PT_NUM_FAST)
+        hipLaunchKernelGGL(k_camera_rays<true>, dim3(blocks_for(n)), dim3(BLOCK), 0, ctx->stream,
+                           ctx->cam, d_px.p, d_xi.p, (long long)n, d_o.p, d_d.p);
+    else
+        hipLaunchKernelGGL(k_camera_rays<false>, dim3(blocks_for(n)), dim3(BLOCK), 0, ctx->stream,
+                           ctx->cam, d_px.p, d_xi.p, (long long)n, d_o.p, d_d.p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(origin, d_o.p, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dir, d_d.p, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_eval_bsdf(pt_ctx *ctx, const int32_t *type, const float *color, const float *normal,
+                 const float *incident, const float *xi, int64_t n,
+                 float *out_dir, float *out_brdf, int numeric)
+{
+    if (!ctx) return fail(nullptr, PT_E_INVALID, "null context");
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if (n < 0 || n > (1ll << 31)) return fail(ctx, PT_E_LIMIT, "row count %lld out of range", (long long)n);
+    if (n == 0) return PT_OK;
+    if (!type || !color || !normal || !incident || !xi || !out_dir || !out_brdf)
+        return fail(ctx, PT_E_INVALID, "null argument");
+    for (int64_t i = 0; i < n; i++)
+        if (type[i] < PT_DIFFUSE || type[i] > PT_GLASS)
+            return fail(ctx, PT_E_INVALID, "row %lld has unknown material type %d", (long long)i, type[i]);
+    Scratch<int32_t> d_type;
+    Scratch<float> d_col, d_nrm, d_inc, d_xi, d_dir, d_f;
+    if ((rc = upload(ctx, d_type, type, (size_t)n))) return rc;
+    if ((rc = upload(ctx, d_col, color, (size_t)n * 3))) return rc;
+    if ((rc = upload(ctx, d_nrm, normal, (size_t)n * 3))) return rc;
+    if ((rc = upload(ctx, d_inc, incident, (size_t)n * 3))) return rc;
+    if ((rc = upload(ctx, d_xi, xi, (size_t)n * 2))) return rc;
+    if ((rc = dev_alloc(ctx, &d_dir.p, (size_t)n * 3))) return rc;
+    if ((rc = dev_alloc(ctx, &d_f.p, (size_t)n * 3))) return rc;
+    if (numeric & PT_NUM_FAST)
+        hipLaunchKernelGGL(k_eval_bsdf<true>, dim3(blocks_for(n)), dim3(BLOCK), 0, ctx->stream, d_type.p, d_col.p,
+                           d_nrm.p, d_inc.p, d_xi.p, (long long)n, d_dir.p, d_f.p);
+    else
+        hipLaunchKernelGGL(k_eval_bsdf<false>, dim3(blocks_for(n)), dim3(BLOCK), 0, ctx->stream, d_type.p, d_col.p,
+                           d_nrm.p, d_inc.p, d_xi.p, (long long)n, d_dir.p, d_f.p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out_dir, d_dir.p, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(out_brdf, d_f.p, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_eval_brdf(pt_ctx *ctx, const int32_t *type, const float *color, const float *normal,
+                 const float *reflected, int64_t n, float *out_brdf)
+{
+    if (!ctx) return fail(nullptr, PT_E_INVALID, "null context");
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if (n < 0 || n > (1ll << 31)) return fail(ctx, PT_E_LIMIT, "row count %lld out of range", (long long)n);
+    if (n == 0) return PT_OK;
+    if (!type || !color || !normal || !reflected || !out_brdf) return fail(ctx, PT_E_INVALID, "null argument");
+    for (int64_t i = 0; i < n; i++)
+        if (type[i] < PT_DIFFUSE || type[i] > PT_GLASS)
+            return fail(ctx, PT_E_INVALID, "row %lld has unknown material type %d", (long long)i, type[i]);
+    Scratch<int32_t> d_type;
+    Scratch<float> d_col, d_nrm, d_refl, d_f;
+    if ((rc = upload(ctx, d_type, type, (size_t)n))) return rc;
+    if ((rc = upload(ctx, d_col, color, (size_t)n * 3))) return rc;
+    if ((rc = upload(ctx, d_nrm, normal, (size_t)n * 3))) return rc;
+    if ((rc = upload(ctx, d_refl, reflected, (size_t)n * 3))) return rc;
+    if ((rc = dev_alloc(ctx, &d_f.p, (size_t)n * 3))) return rc;
+    hipLaunchKernelGGL(k_eval_brdf, dim3(blocks_for(n)), dim3(BLOCK), 0, ctx->stream, d_type.p, d_col.p,
+                       d_nrm.p, d_refl.p, (long long)n, d_f.p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out_brdf, d_f.p, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_rng_uniform(pt_ctx *ctx, uint64_t seed, const uint32_t *pixel, const uint32_t *sample,
+                   const uint32_t *draw, int64_t n, float *out)
+{
+    if (!ctx) return fail(nullptr, PT_E_INVALID, "null context");
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if (n < 0 || n > (1ll << 31)) return fail(ctx, PT_E_LIMIT, "count %lld out of range", (long long)n);
+    if (n == 0) return PT_OK;
+    if (!pixel || !sample || !draw || !out) return fail(ctx, PT_E_INVALID, "null argument");
+    Scratch<uint32_t> d_p, d_s, d_d;
+    Scratch<float> d_out;
+    if ((rc = upload(ctx, d_p, pixel, (size_t)n))) return rc;
+    if ((rc = upload(ctx, d_s, sample, (size_t)n))) return rc;
+    if ((rc = upload(ctx, d_d, draw, (size_t)n))) return rc;
+    if ((rc = dev_alloc(ctx, &d_out.p, (size_t)n))) return rc;
+    hipLaunchKernelGGL(k_rng_uniform, dim3(blocks_for(n)), dim3(BLOCK), 0, ctx->stream, host_seed_mix(seed),
+                       d_p.p, d_s.p, d_d.p, (long long)n, d_out.p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out, d_out.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_get_counters(pt_ctx *ctx, pt_counters *out)
+{
+    if (!ctx) return fail(nullptr, PT_E_INVALID, "null context");
+    if (!out) return fail(ctx, PT_E_INVALID, "out is null");
+    if (!ctx->last_valid) return fail(ctx, PT_E_INVALID, "nothing rendered yet");
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if (ctx->last_pending) {
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev[2]));
+        float ms_kernel = 0, ms_total = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms_kernel, ctx->ev[0], ctx->ev[1]));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms_total, ctx->ev[0], ctx->ev[2]));
+        unsigned long long seg = 0;
+        HIP_TRY(ctx, hipMemcpy(&seg, ctx->d_queue + 2, 8, hipMemcpyDeviceToHost));
+        ctx->last.segments = seg;
+        ctx->last.tests = seg * (uint64_t)ctx->n_surfaces;
+        ctx->last.kernel_ms = ms_kernel;
+        ctx->last.total_ms = ms_total;
+        ctx->last.flops = (double)seg * (63.0 * ctx->n_tri + 18.0 * ctx->n_sph);
+        ctx->last_pending = false;
+    }
+    *out = ctx->last;
+    return PT_OK;
+}
+
+}  // extern "C"

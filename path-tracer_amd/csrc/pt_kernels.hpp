@@ -1,0 +1,281 @@
+// gfx950 kernels of the render step.  Included by pt_amd.hip only.
+#pragma once
+
+#include "pt_device.hpp"
+
+namespace ptd {
+
+constexpr int BLOCK = 256;           // 4 waves of 64
+constexpr uint32_t POOL_BATCH = 64;  // work items a wave takes from the global queue at a time
+constexpr uint32_t NO_ITEM = 0xFFFFFFFFu;
+constexpr int MAX_DEPTH = 1024;      // PT_MAX_DEPTH
+
+struct RenderParams {
+    Camera cam;
+    const float *geom;        // n_surfaces * GEOM_STRIDE, read through the scalar cache
+    const float *shade;       // n_surfaces * SHADE_STRIDE, staged in LDS
+    int n_surfaces;
+    float bg[3];
+    uint32_t seed_mix;
+    uint32_t first_sample;
+    uint32_t spp;
+    uint32_t chunk_len;       // samples per work item
+    uint32_t n_pixels;
+    uint32_t n_items;         // n_pixels * ceil(spp / chunk_len); item = chunk * n_pixels + pixel
+    float *slabs;             // n_items * 3 partial sums, slab of chunk k at k * n_pixels * 3
+    uint32_t *queue_head;     // zeroed before the launch
+    unsigned long long *stats;  // [0] += segments
+};
+
+// ---------------------------------------------------------------- parity kernels
+
+// One thread per pixel: the ray through the pixel's integer corner, closest hit.
+template <bool FAST>
+__global__ void __launch_bounds__(BLOCK)
+k_primary_hits(Camera cam, const float *geom_g, int n_surfaces, int32_t *idx, float *dist)
+{
+    const int p = blockIdx.x * BLOCK + threadIdx.x;
+    if (p >= cam.width * cam.height) return;
+    const int x = p % cam.width, y = p / cam.width;
+    const V3 o = v3(cam.pos[0], cam.pos[1], cam.pos[2]);
+    const V3 d = ray_direction_by_pixel<FAST>(cam, (float)x, (float)y);
+    const Hit h = closest_intersection<FAST>(as_constant(geom_g), n_surfaces, o, d);
+    idx[p] = h.idx;
+    dist[p] = h.idx < 0 ? 0.0f : h.dist;
+}
+
+template <bool FAST>
+__global__ void __launch_bounds__(BLOCK)
+k_intersect_rays(const float *geom_g, int n_surfaces, const float *org, const float *dir,
+                 long long n, int32_t *idx, float *dist, float *point)
+{
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const V3 o = v3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
+    const V3 d = v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+    const Hit h = closest_intersection<FAST>(as_constant(geom_g), n_surfaces, o, d);
+    idx[i] = h.idx;
+    dist[i] = h.idx < 0 ? 0.0f : h.dist;
+    V3 pt = v3(0, 0, 0);
+    if (h.idx >= 0) pt = Num<FAST>::along(o, d, h.t);
+    point[3 * i] = pt.x; point[3 * i + 1] = pt.y; point[3 * i + 2] = pt.z;
+}
+
+template <bool FAST>
+__global__ void __launch_bounds__(BLOCK)
+k_camera_rays(Camera cam, const int32_t *px, const float *xi, long long n, float *org, float *dir)
+{
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    V3 o, d;
+    camera_ray<FAST>(cam, px[2 * i], px[2 * i + 1], xi[4 * i], xi[4 * i + 1], xi[4 * i + 2],
+                     xi[4 * i + 3], o, d);
+    org[3 * i] = o.x; org[3 * i + 1] = o.y; org[3 * i + 2] = o.z;
+    dir[3 * i] = d.x; dir[3 * i + 1] = d.y; dir[3 * i + 2] = d.z;
+}
+
+template <bool FAST>
+__global__ void __launch_bounds__(BLOCK)
+k_eval_bsdf(const int32_t *type, const float *color, const float *normal, const float *incident,
+            const float *xi, long long n, float *out_dir, float *out_brdf)
+{
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const V3 nrm = v3(normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]);
+    const V3 inc = v3(incident[3 * i], incident[3 * i + 1], incident[3 * i + 2]);
+    const V3 col = v3(color[3 * i], color[3 * i + 1], color[3 * i + 2]);
+    const V3 d = sample_pdf<FAST>(type[i], nrm, inc, xi[2 * i], xi[2 * i + 1]);
+    const V3 f = brdf<FAST>(type[i], col, nrm, d);
+    out_dir[3 * i] = d.x; out_dir[3 * i + 1] = d.y; out_dir[3 * i + 2] = d.z;
+    out_brdf[3 * i] = f.x; out_brdf[3 * i + 1] = f.y; out_brdf[3 * i + 2] = f.z;
+}
+
+__global__ void __launch_bounds__(BLOCK)
+k_eval_brdf(const int32_t *type, const float *color, const float *normal, const float *reflected,
+            long long n, float *out_brdf)
+{
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const V3 nrm = v3(normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]);
+    const V3 refl = v3(reflected[3 * i], reflected[3 * i + 1], reflected[3 * i + 2]);
+    const V3 col = v3(color[3 * i], color[3 * i + 1], color[3 * i + 2]);
+    const V3 f = brdf<false>(type[i], col, nrm, refl);
+    out_brdf[3 * i] = f.x; out_brdf[3 * i + 1] = f.y; out_brdf[3 * i + 2] = f.z;
+}
+
+__global__ void __launch_bounds__(BLOCK)
+k_rng_uniform(uint32_t seed_mix, const uint32_t *pixel, const uint32_t *sample,
+              const uint32_t *draw, long long n, float *out)
+{
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const Rng r = rng_path(seed_mix, pixel[i], sample[i]);
+    out[i] = rng_at(r, draw[i]);
+}
+
+// ---------------------------------------------------------------- megakernel
+
+// Persistent lanes.  A lane owns one work item (pixel, chunk of samples) at a
+// time, traces its paths one segment per loop iteration, and starts the next
+// path - or fetches the next item - in the iteration after a path ends, so
+// lanes of a wave stay busy whatever the lengths of their paths.  Items come
+// from a global counter, POOL_BATCH at a time per wave, and are handed to
+// lanes from a wave-uniform pool.  A lane leaves the loop when the queue is
+// empty: every wave reaches that state, so the grid always drains.
+template <bool FAST>
+__global__ void __launch_bounds__(BLOCK)
+k_render_mega(RenderParams P)
+{
+    using N = Num<FAST>;
+    extern __shared__ __align__(16) float lds_shade[];
+    for (int i = threadIdx.x; i < P.n_surfaces * SHADE_STRIDE; i += BLOCK)
+        lds_shade[i] = P.shade[i];
+    __syncthreads();
+
+    const cfloat_p geom = as_constant(P.geom);
+    const uint32_t lane = __lane_id();
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+
+    // wave-uniform work pool [pool_next, pool_end)
+    uint32_t pool_next = 0, pool_end = 0;
+    bool drained = false;
+
+    bool have_item = false, need_path = true;
+    uint32_t item = 0, pixel = 0, s = 0, s_end = 0;
+    int px = 0, py = 0, depth = 0;
+    V3 sum = v3(0, 0, 0), col = v3(0, 0, 0), thr = v3(1, 1, 1);
+    V3 o = v3(0, 0, 0), d = v3(0, 0, 1);
+    Rng rng = {0, 0, 0};
+    unsigned long long n_seg = 0;
+
+    for (;;) {
+        const bool want = need_path && s == s_end;
+        if (__any(want)) {                      // wave-uniform: every live lane enters
+            if (want && have_item) {
+                float *dst = P.slabs + 3ull * item;
+                dst[0] = sum.x; dst[1] = sum.y; dst[2] = sum.z;
+                have_item = false;
+            }
+            const unsigned long long mask = __ballot(want);
+            uint32_t cnt = (uint32_t)__popcll(mask);
+            const uint32_t rank = (uint32_t)__popcll(mask & lanes_below);
+            uint32_t got = NO_ITEM;
+            const uint32_t avail = pool_end - pool_next;
+            if (want && rank < avail) got = pool_next + rank;
+            if (cnt <= avail) {
+                pool_next += cnt;
+            } else {
+                cnt -= avail;                   // 1..64 lanes still without an item
+                uint32_t base = P.n_items;
+                if (!drained) {
+                    uint32_t b = 0;
+                    if (lane == (uint32_t)__ffsll((long long)__ballot(1)) - 1u)
+                        b = atomicAdd(P.queue_head, POOL_BATCH);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                }
+                uint32_t end = base + POOL_BATCH;
+                if (base >= P.n_items) { base = end = P.n_items; drained = true; }
+                else if (end > P.n_items) end = P.n_items;
+                if (want && rank >= avail && base + (rank - avail) < end) got = base + (rank - avail);
+                pool_next = base + cnt < end ? base + cnt : end;
+                pool_end = end;
+            }
+            if (want) {
+                if (got == NO_ITEM) break;      // queue empty: this lane retires
+                item = got;
+                have_item = true;
+                const uint32_t chunk = item / P.n_pixels;
+                pixel = item - chunk * P.n_pixels;
+                px = (int)(pixel % (uint32_t)P.cam.width);
+                py = (int)(pixel / (uint32_t)P.cam.width);
+                s = P.first_sample + chunk * P.chunk_len;
+                const uint32_t last = P.first_sample + P.spp;
+                s_end = s + P.chunk_len < last ? s + P.chunk_len : last;
+                sum = v3(0, 0, 0);
+            }
+        }
+        if (need_path) {                        // trace_rays' per-pixel set-up, main.cpp:120-136
+            rng = rng_path(P.seed_mix, pixel, s);
+            const float xu = rng_next(rng), xv = rng_next(rng);
+            float xr = 0.0f, xp = 0.0f;
+            if (P.cam.dof_on) { xr = rng_next(rng); xp = rng_next(rng); }
+            camera_ray<FAST>(P.cam, px, py, xu, xv, xr, xp, o, d);
+            col = v3(0, 0, 0);
+            thr = v3(1, 1, 1);
+            depth = 0;
+            need_path = false;
+        }
+
+        // one iteration of trace_ray's loop, main.cpp:84-109
+        const Hit h = closest_intersection<FAST>(geom, P.n_surfaces, o, d);
+        n_seg++;
+        bool ended;
+        if (h.idx < 0) {
+            col = v3(N::mad(P.bg[0], thr.x, col.x), N::mad(P.bg[1], thr.y, col.y),
+                     N::mad(P.bg[2], thr.z, col.z));
+            ended = true;
+        } else {
+            const float4 r0 = *reinterpret_cast<const float4 *>(lds_shade + h.idx * SHADE_STRIDE);
+            const float4 r1 = *reinterpret_cast<const float4 *>(lds_shade + h.idx * SHADE_STRIDE + 4);
+            const float4 r2 = *reinterpret_cast<const float4 *>(lds_shade + h.idx * SHADE_STRIDE + 8);
+            const int flags = __builtin_bit_cast(int, r0.w);
+            const int type = flags & 0xff;
+            const V3 point = N::along(o, d, h.t);
+            V3 normal = v3(r2.x, r2.y, r2.z);
+            if (flags >> 8) normal = N::normalize(point - normal);   // sphere, surface.hpp:86-88
+            float xi0 = 0.0f, xi1 = 0.0f;
+            if (type == 0) { xi0 = rng_next(rng); xi1 = rng_next(rng); }
+            else if (type == 2) { xi0 = rng_next(rng); }
+            const V3 new_dir = sample_pdf<FAST>(type, normal, d, xi0, xi1);
+            o = point;
+            col = v3(N::mad(r1.x, thr.x, col.x), N::mad(r1.y, thr.y, col.y), N::mad(r1.z, thr.z, col.z));
+            thr = thr * brdf<FAST>(type, v3(r0.x, r0.y, r0.z), normal, new_dir);
+            d = new_dir;
+            ended = false;
+            if (depth >= 5) {                   // russian roulette, main.cpp:97-104
+                if (depth + 1 >= MAX_DEPTH) {
+                    ended = true;
+                } else {
+                    float m = thr.y < thr.z ? thr.z : thr.y;
+                    m = thr.x < m ? m : thr.x;
+                    const float p = m < 0.0f ? 0.0f : (0.95f < m ? 0.95f : m);
+                    if (rng_next(rng) > p) ended = true;
+                    else thr = thr * N::div(1.0f, p);
+                }
+            }
+            depth++;
+        }
+        if (ended) {
+            sum = sum + col;                    // buffer[u][v] += color, main.cpp:139
+            s++;
+            need_path = true;
+        }
+    }
+    atomicAdd(P.stats, n_seg);
+}
+
+// accum[p] += slab_0[p] + slab_1[p] + ... in chunk order (n = n_pixels * 3 floats per slab)
+__global__ void __launch_bounds__(BLOCK)
+k_reduce_slabs(const float *slabs, uint32_t n_chunks, size_t n, float *accum)
+{
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float a = accum[i];
+    for (uint32_t k = 0; k < n_chunks; k++) a += slabs[(size_t)k * n + i];
+    accum[i] = a;
+}
+
+// to_ldr, src/main.cpp:146-148, on sum / float(TOTAL_SAMPLES) (main.cpp:160),
+// then the Uint8 truncation of sdl_helpers.hpp:68-70.
+__global__ void __launch_bounds__(BLOCK)
+k_tonemap(const float *accum, size_t n, float total_samples, uint8_t *out)
+{
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float x = accum[i] / total_samples;
+    const float c = fminf(fmaxf(x, 0.0f), 1.0f);
+    const float v = (float)((double)(powf(c, 1 / 2.2f) * 255) + 0.5);
+    out[i] = (uint8_t)v;
+}
+
+}  // namespace ptd

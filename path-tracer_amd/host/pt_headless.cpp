@@ -1,0 +1,109 @@
+// The reference's main loop (src/main.cpp:296-326) without a window: build a
+// scene, call trace_rays once per pass, report progress every 10 passes as
+// log() does (src/main.cpp:275-277), stop after a fixed number of passes (the
+// reference's -exit stops at 100) and write the tone-mapped image as a PPM.
+//
+//   pt_headless [-scene NAME] [-width W] [-height H] [-passes N] [-batch B]
+//               [-fast] [-out FILE.ppm]
+//
+// -batch B > 0 renders B samples per pixel in one GPU call per pass through
+// pt::Renderer, keeping the sums on the device, instead of one sample per
+// trace_rays call.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+
+#include "pt_render.hpp"
+#include "pt_scenes.hpp"
+
+static bool write_ppm(const std::string &path, int width, int height, const std::vector<uint8_t> &rgb)
+{
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    std::fprintf(f, "P6\n%d %d\n255\n", width, height);
+    const bool ok = std::fwrite(rgb.data(), 1, rgb.size(), f) == rgb.size();
+    std::fclose(f);
+    return ok;
+}
+
+int main(int argc, char *argv[])
+{
+    std::string scene_name = "orange_plane", out;   // the reference's default scene (src/main.cpp:311)
+    int width = 356, height = 200, passes = 100, batch = 0;
+    bool fast = false;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        auto next = [&](const char *what) -> const char * {
+            if (i + 1 >= argc) { std::cerr << "missing value for " << what << std::endl; std::exit(2); }
+            return argv[++i];
+        };
+        if (a == "-scene") scene_name = next("-scene");
+        else if (a == "-width") width = std::atoi(next("-width"));
+        else if (a == "-height") height = std::atoi(next("-height"));
+        else if (a == "-passes") passes = std::atoi(next("-passes"));
+        else if (a == "-batch") batch = std::atoi(next("-batch"));
+        else if (a == "-out") out = next("-out");
+        else if (a == "-fast") fast = true;
+        else { std::cerr << "unknown argument " << a << std::endl; return 2; }
+    }
+    if (width < 1 || height < 1 || passes < 1 || batch < 0) { std::cerr << "bad size" << std::endl; return 2; }
+
+    try {
+        set_screen_size(width, height);
+        std::optional<Scene> scene;
+        if (!Scenes::by_name(scene_name.c_str(), scene)) {
+            std::cerr << "unknown scene " << scene_name << std::endl;
+            return 2;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<uint8_t> rgb;
+        double mean[3] = {0, 0, 0};
+        if (batch == 0) {
+            BUFFER buffer(width, std::vector<vec3>(height, vec3()));
+            for (int pass = 0; pass < passes; pass++) {
+                scene->camera.update();
+                trace_rays(*scene, buffer);
+                if (TOTAL_SAMPLES % 10 == 0) std::cerr << TOTAL_SAMPLES << std::endl;
+            }
+            for (const auto &column : buffer)
+                for (const vec3 &c : column) { mean[0] += c.x; mean[1] += c.y; mean[2] += c.z; }
+            if (!out.empty()) {               // draw(): tone-map buffer / TOTAL_SAMPLES
+                std::vector<float> sums(static_cast<size_t>(width) * height * 3);
+                for (int u = 0; u < width; u++)
+                    for (int v = 0; v < height; v++) {
+                        float *p = &sums[3 * (static_cast<size_t>(v) * width + u)];
+                        p[0] = buffer[u][v].x; p[1] = buffer[u][v].y; p[2] = buffer[u][v].z;
+                    }
+                pt::Renderer &r = pt::default_renderer();
+                r.write_sums(sums, TOTAL_SAMPLES);
+                rgb = r.tonemap();
+            }
+        } else {
+            pt::Renderer &r = pt::default_renderer();
+            r.sync(*scene, width, height);
+            for (int pass = 0; pass < passes; pass++) {
+                r.render(static_cast<uint32_t>(batch), 1, fast ? PT_NUM_FAST : PT_NUM_EXACT);
+                TOTAL_SAMPLES += batch;
+                if ((pass + 1) % 10 == 0) std::cerr << TOTAL_SAMPLES << std::endl;
+            }
+            const std::vector<float> sums = r.read_sums();
+            for (size_t i = 0; i < sums.size(); i += 3) { mean[0] += sums[i]; mean[1] += sums[i + 1]; mean[2] += sums[i + 2]; }
+            if (!out.empty()) rgb = r.tonemap();
+        }
+        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const double n = static_cast<double>(width) * height * TOTAL_SAMPLES;
+        std::printf("scene=%s size=%dx%d samples_per_pixel=%u seconds=%.3f Msamples_per_s=%.2f mean_rgb=%.6f,%.6f,%.6f\n",
+                    scene_name.c_str(), width, height, TOTAL_SAMPLES, secs, n / secs / 1e6,
+                    mean[0] / n, mean[1] / n, mean[2] / n);
+        if (!out.empty()) {
+            if (!write_ppm(out, width, height, rgb)) { std::cerr << "cannot write " << out << std::endl; return 1; }
+            std::cerr << "saved image to " << out << std::endl;
+        }
+    } catch (const pt::Error &e) {
+        std::cerr << "render failed (" << e.code << "): " << e.what() << std::endl;
+        return 1;
+    }
+    return 0;
+}

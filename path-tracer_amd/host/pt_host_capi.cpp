@@ -1,0 +1,50 @@
+// C entry points over the C++ host scene model, so that non-C++ hosts (the
+// Python tests and the benchmark driver) build scenes through the same code a
+// C++ caller uses: Scenes::*, Camera's matrix, pt::flatten.
+#include "pt_render.hpp"
+#include "pt_scenes.hpp"
+
+extern "C" {
+
+// Flattens built-in scene `name` for a width x height image (focal length =
+// height pixels).  surfaces/materials hold `capacity` entries.  Returns 0,
+// -1 for an unknown name, -2 if capacity is too small.
+int pt_host_builtin_scene(const char *name, int width, int height, pt_surface *surfaces,
+                          pt_material *materials, int32_t capacity, int32_t *n_surfaces,
+                          float bg[3], pt_camera *camera)
+{
+    set_screen_size(width, height);
+    std::optional<Scene> scene;
+    if (!Scenes::by_name(name, scene)) return -1;
+    const pt::FlatScene flat = pt::flatten(*scene, width, height);
+    if (static_cast<int32_t>(flat.surfaces.size()) > capacity) return -2;
+    for (size_t i = 0; i < flat.surfaces.size(); i++) {
+        surfaces[i] = flat.surfaces[i];
+        materials[i] = flat.materials[i];
+    }
+    *n_surfaces = static_cast<int32_t>(flat.surfaces.size());
+    std::memcpy(bg, flat.bg, sizeof flat.bg);
+    *camera = flat.camera;
+    return 0;
+}
+
+// Camera pose -> rotation matrix through class Camera (src/camera.hpp:20-39).
+// add_offset != 0 uses the three-argument constructor's OFFSET.
+void pt_host_camera_matrix(float rot_x, float rot_y, int add_offset, float out_rot[9])
+{
+    Camera cam;                       // pose (0,0), no offset
+    if (add_offset) {
+        cam = Camera(vec3(0, 0, 0), vec2(rot_x, rot_y), 1.0f);
+    } else {
+        cam.rotate(rot_x, rot_y);
+        cam.update();
+    }
+    const mat3 &r = cam.get_rotation_matrix();
+    for (int c = 0; c < 3; c++) {
+        out_rot[3 * c + 0] = r[c].x;
+        out_rot[3 * c + 1] = r[c].y;
+        out_rot[3 * c + 2] = r[c].z;
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,267 @@
+// The render step on the GPU behind the reference's call surface.
+//
+//   void trace_rays(Scene&, BUFFER&)   -- src/main.cpp:114-143: adds one sample
+//       per pixel to the host buffer and increments TOTAL_SAMPLES.
+//   pt::Renderer                        -- the batched form: the running sums
+//       stay in device memory, many samples per call, read back on demand.
+//
+// Both flatten the Scene into the plain arrays of include/pt_amd.h and call
+// the HIP library; nothing here computes radiance on the CPU.  Include this
+// header in exactly one translation unit (it defines TOTAL_SAMPLES, as the
+// reference's main.cpp does).
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <typeinfo>
+
+#include "pt_types.hpp"
+
+// src/main.cpp:31-32
+typedef std::vector<std::vector<vec3>> BUFFER;   // buffer[u = x][v = y], running sums
+inline unsigned TOTAL_SAMPLES = 0;
+
+namespace pt {
+
+class Error : public std::runtime_error {
+  public:
+    Error(int code, const std::string &what) : std::runtime_error(what), code(code) {}
+    int code;
+};
+
+// A Scene in the flat form of the C ABI.
+struct FlatScene {
+    std::vector<pt_surface> surfaces;
+    std::vector<pt_material> materials;   // one per surface: each Surface owns its Material by value
+    float bg[3];
+    pt_camera camera;
+
+    bool same_geometry(const FlatScene &o) const
+    {
+        return surfaces.size() == o.surfaces.size() && std::memcmp(bg, o.bg, sizeof bg) == 0 &&
+               (surfaces.empty() ||
+                (std::memcmp(surfaces.data(), o.surfaces.data(), surfaces.size() * sizeof(pt_surface)) == 0 &&
+                 std::memcmp(materials.data(), o.materials.data(), materials.size() * sizeof(pt_material)) == 0));
+    }
+    bool same_camera(const FlatScene &o) const { return std::memcmp(&camera, &o.camera, sizeof camera) == 0; }
+};
+
+inline FlatScene flatten(const Scene &scene, int width, int height)
+{
+    FlatScene f{};
+    f.surfaces.reserve(scene.surfaces.size());
+    f.materials.reserve(scene.surfaces.size());
+    for (const auto &ptr : scene.surfaces) {          // scene order is kept: it breaks distance ties
+        pt_surface s = ptr->flat();
+        s.material = static_cast<int32_t>(f.materials.size());
+        pt_material m{};
+        m.type = ptr->material.type;
+        const vec3 &c = ptr->material.color, &e = ptr->material.emittance;
+        m.color[0] = c.x; m.color[1] = c.y; m.color[2] = c.z;
+        m.emittance[0] = e.x; m.emittance[1] = e.y; m.emittance[2] = e.z;
+        f.surfaces.push_back(s);
+        f.materials.push_back(m);
+    }
+    f.bg[0] = scene.BG_COLOR.x; f.bg[1] = scene.BG_COLOR.y; f.bg[2] = scene.BG_COLOR.z;
+    const Camera &cam = scene.camera;
+    const vec3 &p = cam.get_position();
+    f.camera.pos[0] = p.x; f.camera.pos[1] = p.y; f.camera.pos[2] = p.z;
+    const mat3 &r = cam.get_rotation_matrix();
+    for (int c = 0; c < 3; c++) {
+        f.camera.rot[3 * c + 0] = r[c].x;
+        f.camera.rot[3 * c + 1] = r[c].y;
+        f.camera.rot[3 * c + 2] = r[c].z;
+    }
+    f.camera.focal = cam.get_focal_length();
+    f.camera.width = width;
+    f.camera.height = height;
+    f.camera.dof_on = scene.DOF_on ? 1 : 0;
+    f.camera.dof_focal_length = scene.DOF_focal_length;
+    f.camera.dof_aperture = scene.DOF_aperture_size;
+    return f;
+}
+
+// RAII owner of one GPU context.
+class Renderer {
+    pt_ctx *ctx_ = nullptr;
+    FlatScene loaded_{};
+    bool have_scene_ = false;
+    uint32_t next_sample_ = 0;
+
+    void check(int rc) const
+    {
+        if (rc != PT_OK) throw Error(rc, pt_last_error(ctx_));
+    }
+
+  public:
+    explicit Renderer(int device = 0)
+    {
+        const int rc = pt_create(device, &ctx_);
+        if (rc != PT_OK) throw Error(rc, pt_global_error());
+    }
+    ~Renderer() { pt_destroy(ctx_); }
+    Renderer(const Renderer &) = delete;
+    Renderer &operator=(const Renderer &) = delete;
+
+    pt_ctx *context() const { return ctx_; }
+
+    // Uploads whatever changed since the last call.  A changed camera, DOF
+    // setting, image size or scene clears the accumulated image, the condition
+    // under which the reference clears its buffer (src/main.cpp:258-269).
+    // Returns true when the image was cleared.
+    bool sync(const Scene &scene, int width, int height)
+    {
+        FlatScene f = flatten(scene, width, height);
+        bool cleared = false;
+        if (!have_scene_ || !f.same_geometry(loaded_)) {
+            check(pt_set_scene(ctx_, f.surfaces.data(), static_cast<int32_t>(f.surfaces.size()),
+                               f.materials.data(), static_cast<int32_t>(f.materials.size()), f.bg));
+            cleared = true;
+        }
+        if (cleared || !f.same_camera(loaded_)) {
+            check(pt_set_camera(ctx_, &f.camera));   // clears
+            cleared = true;
+        }
+        loaded_ = std::move(f);
+        have_scene_ = true;
+        return cleared;
+    }
+
+    void clear() { check(pt_clear(ctx_)); }
+
+    // Adds spp samples per pixel; sample numbers continue across calls so no
+    // two passes repeat a random stream.
+    void render(uint32_t spp, uint64_t seed = 1, int mode = PT_MODE_MEGAKERNEL | PT_NUM_EXACT)
+    {
+        check(pt_render(ctx_, spp, next_sample_, seed, mode));
+        next_sample_ += spp;
+    }
+
+    uint64_t total_samples() const
+    {
+        uint64_t n = 0;
+        check(pt_read_accum(ctx_, nullptr, &n));
+        return n;
+    }
+
+    // Running sums, row-major (pixel (u,v) at 3*(v*width+u)).
+    std::vector<float> read_sums() const
+    {
+        std::vector<float> sums(static_cast<size_t>(loaded_.camera.width) * loaded_.camera.height * 3);
+        check(pt_read_accum(ctx_, sums.data(), nullptr));
+        return sums;
+    }
+
+    // Replaces the device image with host sums (row-major) and their sample count.
+    void write_sums(const std::vector<float> &sums, uint64_t total_samples)
+    {
+        if (sums.size() != static_cast<size_t>(loaded_.camera.width) * loaded_.camera.height * 3)
+            throw Error(PT_E_INVALID, "write_sums: size does not match the image");
+        check(pt_write_accum(ctx_, sums.data(), total_samples));
+    }
+
+    // 8-bit image as the reference's draw() shows it (src/main.cpp:146-162).
+    std::vector<uint8_t> tonemap() const
+    {
+        std::vector<uint8_t> rgb(static_cast<size_t>(loaded_.camera.width) * loaded_.camera.height * 3);
+        check(pt_tonemap_rgb8(ctx_, rgb.data()));
+        return rgb;
+    }
+
+    pt_counters counters() const
+    {
+        pt_counters c{};
+        check(pt_get_counters(ctx_, &c));
+        return c;
+    }
+};
+
+inline Renderer &default_renderer()
+{
+    static Renderer r(0);
+    return r;
+}
+
+// ---- single-query gateways used by Material and Surface methods ----
+
+inline vec3 gpu_sample_pdf(MaterialType type, vec3 normal, vec3 incident, float xi0, float xi1)
+{
+    const int32_t t = type;
+    const float col[3] = {1, 1, 1}, n[3] = {normal.x, normal.y, normal.z};
+    const float in[3] = {incident.x, incident.y, incident.z}, xi[2] = {xi0, xi1};
+    float dir[3], f[3];
+    Renderer &r = default_renderer();
+    const int rc = pt_eval_bsdf(r.context(), &t, col, n, in, xi, 1, dir, f, PT_NUM_EXACT);
+    if (rc != PT_OK) throw Error(rc, pt_last_error(r.context()));
+    return vec3(dir[0], dir[1], dir[2]);
+}
+
+inline vec3 gpu_brdf(MaterialType type, vec3 color, vec3 normal, vec3 reflected)
+{
+    const int32_t t = type;
+    const float col[3] = {color.x, color.y, color.z}, n[3] = {normal.x, normal.y, normal.z};
+    const float refl[3] = {reflected.x, reflected.y, reflected.z};
+    float f[3];
+    Renderer &r = default_renderer();
+    const int rc = pt_eval_brdf(r.context(), &t, col, n, refl, 1, f);
+    if (rc != PT_OK) throw Error(rc, pt_last_error(r.context()));
+    return vec3(f[0], f[1], f[2]);
+}
+
+inline bool gpu_intersect(const pt_surface &surface, vec3 start, vec3 dir, vec3 &point, float &distance)
+{
+    // A context of its own, so that one-surface queries never disturb the scene
+    // loaded in the default renderer.
+    static Renderer probe(0);
+    pt_surface s = surface;
+    s.material = 0;
+    pt_material m{};
+    m.type = PT_DIFFUSE;
+    const float bg[3] = {0, 0, 0};
+    int rc = pt_set_scene(probe.context(), &s, 1, &m, 1, bg);
+    if (rc != PT_OK) throw Error(rc, pt_last_error(probe.context()));
+    const float o[3] = {start.x, start.y, start.z}, d[3] = {dir.x, dir.y, dir.z};
+    int32_t idx = -1;
+    float pt3[3] = {0, 0, 0};
+    rc = pt_intersect_rays(probe.context(), o, d, 1, &idx, &distance, pt3);
+    if (rc != PT_OK) throw Error(rc, pt_last_error(probe.context()));
+    point = vec3(pt3[0], pt3[1], pt3[2]);
+    return idx == 0;
+}
+
+inline float gpu_uniform()
+{
+    static uint32_t draw = 0;
+    const uint32_t zero = 0, d = draw++;
+    float out = 0;
+    Renderer &r = default_renderer();
+    const int rc = pt_rng_uniform(r.context(), 0x5eedull, &zero, &zero, &d, 1, &out);
+    if (rc != PT_OK) throw Error(rc, pt_last_error(r.context()));
+    return out;
+}
+
+}  // namespace pt
+
+// src/main.cpp:114-143.  buffer is indexed buffer[u][v] with u the column;
+// its size gives the image size.  One sample per pixel is added to it and
+// TOTAL_SAMPLES is incremented, exactly the reference's observable effect.
+inline void trace_rays(Scene &scene, BUFFER &buffer, uint32_t spp = 1)
+{
+    if (buffer.empty() || buffer[0].empty() || spp == 0) return;
+    const int width = static_cast<int>(buffer.size()), height = static_cast<int>(buffer[0].size());
+    pt::Renderer &r = pt::default_renderer();
+    r.sync(scene, width, height);
+    r.clear();                                   // the host buffer holds the running sums
+    r.render(spp);
+    const std::vector<float> sums = r.read_sums();
+    for (int u = 0; u < width; u++) {
+        std::vector<vec3> &column = buffer[u];
+        for (int v = 0; v < height; v++) {
+            const float *p = &sums[3 * (static_cast<size_t>(v) * width + u)];
+            column[v] += vec3(p[0], p[1], p[2]);
+        }
+    }
+    TOTAL_SAMPLES += spp;
+}

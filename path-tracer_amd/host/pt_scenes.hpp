@@ -1,0 +1,160 @@
+// The reference's seven built-in scenes (src/scene.hpp:32-203) as data for the
+// host scene model: same names, same surface order (the surface index is the
+// tie-break of the closest-hit search), same constants.  Every camera uses a
+// focal length of SCREEN_HEIGHT pixels and the constructor that adds OFFSET.
+#pragma once
+
+#include <cstring>
+
+#include "pt_types.hpp"
+
+namespace Scenes {
+
+namespace detail {
+
+using SurfaceList = std::vector<std::unique_ptr<Surface>>;
+
+inline Material diffuse(float r, float g, float b, float emit = 0.0f)
+{
+    return Material(DIFFUSE, vec3(r, g, b), emit * vec3(1, 1, 1));
+}
+
+// The five wall triangles shared by both Cornell boxes: floor, left, right,
+// ceiling, back.  The box is open towards the camera (walls start at z = -1).
+inline void cornell_walls(SurfaceList &out, const Material &floor, const Material &left,
+                          const Material &right, const Material &ceiling, const Material &back)
+{
+    add_surface(out, Triangle(vec3(-2, 1, -1), vec3(0, 1, 10), vec3(2, 1, -1), floor));
+    add_surface(out, Triangle(vec3(-1, -2, -1), vec3(-1, 0, 10), vec3(-1, 2, -1), left));
+    add_surface(out, Triangle(vec3(1, -2, -1), vec3(1, 2, -1), vec3(1, 0, 10), right));
+    add_surface(out, Triangle(vec3(-2, -1, -1), vec3(2, -1, -1), vec3(0, -1, 10), ceiling));
+    add_surface(out, Triangle(vec3(-2, 1, 1), vec3(0, -10, 1), vec3(2, 1, 1), back));
+}
+
+inline Scene finish(SurfaceList &surfaces, vec3 cam_pos, vec2 cam_rot, vec3 background, bool dof,
+                    float aperture = 0.15, float focus = 2)
+{
+    Camera camera(cam_pos, cam_rot, static_cast<float>(SCREEN_HEIGHT));
+    return Scene(camera, background, surfaces, dof, aperture, focus);
+}
+
+}  // namespace detail
+
+// Three large spheres on a huge floor sphere, coloured lights far away; DOF on.
+inline Scene dof_demo()
+{
+    using namespace detail;
+    SurfaceList s;
+    const float R = 1000;
+    add_surface(s, Sphere(vec3(0, R, 0), R, Material(DIFFUSE, vec3(1, 1, 1), 0.5f * vec3(1, 1, 1))));
+    add_surface(s, Sphere(vec3(-1, -1, 1), 1, Material(DIFFUSE, vec3(0.5, 0, 1))));
+    add_surface(s, Sphere(vec3(1.5, -1, 2), 1, Material(DIFFUSE, vec3(1, 0, 0.5))));
+    add_surface(s, Sphere(vec3(-35, -20, 50), 1, Material(DIFFUSE, vec3(1, 0, 0), 1.0f * vec3(1, 0, 0))));
+    add_surface(s, Sphere(vec3(3, -12, 50), 1, Material(DIFFUSE, vec3(0, 0, 1), 1.0f * vec3(0, 0, 1))));
+    add_surface(s, Sphere(vec3(35, -16, 50), 1, Material(DIFFUSE, vec3(1, 0, 1), 1.0f * vec3(1, 0, 1))));
+    return finish(s, vec3(0, -1, -3), vec2(0, 0), 0.1f * vec3(1, 1, 1), true, 0.3, 5);
+}
+
+// Eleven spheres in a row shading from red to yellow under a white sky.
+inline Scene test()
+{
+    using namespace detail;
+    SurfaceList s;
+    for (int i = 0; i <= 10; i++) {
+        const float green = i / 10.0;
+        add_surface(s, Sphere(vec3(i, -0.5, 0), 0.5, Material(DIFFUSE, vec3(1, green, 0))));
+    }
+    return finish(s, vec3(5, 0, -7), vec2(0, 0), vec3(1, 1, 1), false);
+}
+
+// Mirror, glass and white spheres on an orange ground triangle under a big lamp; DOF on.
+inline Scene orange_plane()
+{
+    using namespace detail;
+    SurfaceList s;
+    add_surface(s, Sphere(vec3(-1.5f, 0.0f, 0.0f), 0.75, Material(MIRROR)));
+    add_surface(s, Sphere(vec3(1.5f, 0.0f, 0.0f), 0.75, Material(GLASS)));
+    add_surface(s, Sphere(vec3(0.0f, 0.0f, 2.0f), 0.75, diffuse(1, 1, 1)));
+    add_surface(s, Sphere(vec3(0.0f, -10.0f, 0.0f), 5, diffuse(1, 1, 1, 5.0f)));
+    add_surface(s, Triangle(vec3(-100, 0.75, 100), vec3(100, 0.75, 100), vec3(0, 0.75, -100),
+                            diffuse(1.00f, 0.40f, 0.00f)));
+    return finish(s, vec3(0, 0, -3), vec2(0, 0), vec3(0, 0, 0), true, 0.15, 5);
+}
+
+// Black, mirror and glass spheres in the corner of a red floor and a lamp wall.
+inline Scene red_corner()
+{
+    using namespace detail;
+    SurfaceList s;
+    add_surface(s, Sphere(vec3(0, -1, 2), 1, diffuse(0.05f, 0.05f, 0.05f)));
+    add_surface(s, Sphere(vec3(-1.25, -1, 0), 1, Material(MIRROR)));
+    add_surface(s, Sphere(vec3(1.25, -1, 0), 1, Material(GLASS)));
+    add_surface(s, Triangle(vec3(0, 0, -100), vec3(-10, 0, 3), vec3(10, 0, 3), diffuse(1.00f, 0.05f, 0.05f)));
+    add_surface(s, Triangle(vec3(0, -100, 3), vec3(-10, 0, 3), vec3(10, 0, 3), diffuse(1, 1, 1, 1.5f)));
+    return finish(s, vec3(0, -4.5, -3), vec2(-M_PI_4, 0), vec3(0, 0, 0), false);
+}
+
+// Two spheres on a dark ground under a pale sky, camera turned round; DOF on.
+inline Scene sunrise()
+{
+    using namespace detail;
+    SurfaceList s;
+    add_surface(s, Triangle(vec3(-100, 0, 100), vec3(100, 0, 100), vec3(0, 0, -100), diffuse(0.05f, 0.05f, 0.05f)));
+    add_surface(s, Sphere(vec3(-2, -1, 0), 1, diffuse(0.95f, 0.95f, 0.95f)));
+    add_surface(s, Sphere(vec3(-1, -1, 7), 1, diffuse(1.00f, 0.40f, 0.00f)));
+    return finish(s, vec3(0, -1, -2), vec2(0, 5.78), vec3(0.7, 0.7, 1), true, 0.2, 9);
+}
+
+// Cornell box with a mirror sphere, a glass sphere and a sphere light that
+// pokes through the ceiling: the benchmark scene.
+inline Scene cornell_2()
+{
+    using namespace detail;
+    SurfaceList s;
+    cornell_walls(s, diffuse(1.00f, 0.05f, 0.05f), diffuse(1, 0.05f, 1), diffuse(1, 1, 0.05f),
+                  diffuse(0.05f, 1, 1), diffuse(1, 1, 1));
+    add_surface(s, Sphere(vec3(-0.32, 0.6, 0.26), 0.4, Material(MIRROR)));
+    add_surface(s, Sphere(vec3(0.35, 0.6, -0.39), 0.4, Material(GLASS)));
+    add_surface(s, Sphere(vec3(0, -1.8, 0), 1, diffuse(1, 1, 1, 2.0f)));
+    return finish(s, vec3(0, 0, -3), vec2(0, 0), 0.0f * vec3(1, 1, 1), false);
+}
+
+// All-diffuse Cornell box lit by its ceiling, with a red sphere and a blue
+// box of ten triangles (no bottom face).
+inline Scene cornell()
+{
+    using namespace detail;
+    SurfaceList s;
+    cornell_walls(s, diffuse(0.05f, 1, 0.05f), diffuse(1, 0.05f, 1), diffuse(1, 1, 0.05f),
+                  diffuse(0.05f, 1, 1, 0.7f), diffuse(1, 1, 1));
+    add_surface(s, Sphere(vec3(0.35, 0.7, -0.39), 0.3, diffuse(1.00f, 0.05f, 0.05f)));
+
+    // box corners: index bit 2 = top (y = -0.189..) else bottom (y = 1); bits 1,0 pick the footprint corner
+    const float foot[4][2] = {{-0.5243243243243243f, -0.1099099099099099f},
+                              {0.04504504504504503f, 0.06666666666666665f},
+                              {-0.7009009009009008f, 0.463063063063063f},
+                              {-0.13153153153153152f, 0.6432432432432433f}};
+    const float y_bottom = 1.0f, y_top = -0.18918918918918926f;
+    vec3 corner[8];
+    for (int i = 0; i < 8; i++) corner[i] = vec3(foot[i & 3][0], i & 4 ? y_top : y_bottom, foot[i & 3][1]);
+    // faces as corner indices, in the reference's order (A..H = 0..7)
+    const int faces[10][3] = {{4, 1, 0}, {4, 5, 1}, {5, 3, 1}, {5, 7, 3}, {7, 2, 3},
+                              {7, 6, 2}, {6, 4, 2}, {4, 0, 2}, {6, 5, 4}, {6, 7, 5}};
+    const Material blue = diffuse(0.05f, 0.05f, 1.00f);
+    for (const auto &f : faces) add_surface(s, Triangle(corner[f[0]], corner[f[1]], corner[f[2]], blue));
+    return finish(s, vec3(0, 0, -3), vec2(0, 0), 0.1f * vec3(1, 1, 1), false);
+}
+
+// Looks a built-in scene up by name; returns false for an unknown name.
+inline bool by_name(const char *name, std::optional<Scene> &out)
+{
+    struct Entry { const char *name; Scene (*make)(); };
+    static const Entry table[] = {{"dof_demo", dof_demo}, {"test", test}, {"orange_plane", orange_plane},
+                                  {"red_corner", red_corner}, {"sunrise", sunrise},
+                                  {"cornell_2", cornell_2}, {"cornell", cornell}};
+    for (const Entry &e : table)
+        if (!std::strcmp(e.name, name)) { out.emplace(e.make()); return true; }
+    return false;
+}
+
+}  // namespace Scenes

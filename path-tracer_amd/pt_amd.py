@@ -1,0 +1,283 @@
+"""ctypes binding of libpt_amd.so, the C ABI declared in include/pt_amd.h.
+
+Thin plumbing only: every method is one C call.  There is no CPU fallback: if
+the HIP library is missing or no gfx950 device is present, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpt_amd.so")
+HOST_LIB_PATH = os.path.join(_HERE, "lib", "libpt_host.so")
+
+SURFACE = np.dtype([("kind", "<i4"), ("material", "<i4"), ("a", "<f4", 3),
+                    ("b", "<f4", 3), ("c", "<f4", 3)])
+MATERIAL = np.dtype([("type", "<i4"), ("color", "<f4", 3), ("emittance", "<f4", 3)])
+CAMERA = np.dtype([("pos", "<f4", 3), ("rot", "<f4", 9), ("focal", "<f4"),
+                   ("width", "<i4"), ("height", "<i4"), ("dof_on", "<i4"),
+                   ("dof_focal_length", "<f4"), ("dof_aperture", "<f4")])
+
+DIFFUSE, MIRROR, GLASS = 0, 1, 2
+TRIANGLE, SPHERE = 0, 1
+MODE_MEGAKERNEL, MODE_WAVEFRONT = 0x0, 0x1
+NUM_EXACT, NUM_FAST = 0x0, 0x10
+MAX_DEPTH = 1024
+
+SCENE_NAMES = ("dof_demo", "test", "orange_plane", "red_corner", "sunrise",
+               "cornell_2", "cornell")
+
+# Every symbol include/pt_amd.h declares.
+ABI_SYMBOLS = (
+    "pt_global_error", "pt_create", "pt_destroy", "pt_last_error", "pt_set_stream",
+    "pt_set_scene", "pt_set_camera", "pt_clear", "pt_render", "pt_render_into",
+    "pt_read_accum", "pt_write_accum", "pt_tonemap_rgb8", "pt_primary_hits", "pt_intersect_rays",
+    "pt_camera_rays", "pt_eval_bsdf", "pt_eval_brdf", "pt_rng_uniform", "pt_get_counters",
+)
+
+
+class Counters(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("tests", C.c_uint64),
+                ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("flops", C.c_double),
+                ("vgprs", C.c_uint32), ("grid_blocks", C.c_uint32)]
+
+
+class PtError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("pt_amd error %d: %s" % (code, message))
+        self.code = code
+
+
+_lib = None
+_host = None
+
+
+def load():
+    """Loads libpt_amd.so; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                "%s is missing: build it with `make -C path-tracer_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        lib.pt_global_error.restype = C.c_char_p
+        lib.pt_last_error.restype = C.c_char_p
+        lib.pt_last_error.argtypes = [C.c_void_p]
+        lib.pt_destroy.restype = None
+        lib.pt_destroy.argtypes = [C.c_void_p]
+        for name in ABI_SYMBOLS:
+            fn = getattr(lib, name)
+            if name not in ("pt_global_error", "pt_last_error", "pt_destroy"):
+                fn.restype = C.c_int
+        _lib = lib
+    return _lib
+
+
+def load_host():
+    """Loads libpt_host.so, the C++ host mirror of the reference's scene types."""
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise FileNotFoundError("%s is missing: build it with `make -C path-tracer_amd/host`"
+                                    % HOST_LIB_PATH)
+        _host = C.CDLL(HOST_LIB_PATH)
+        _host.pt_host_builtin_scene.restype = C.c_int
+    return _host
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class SceneData:
+    """A flattened scene: surfaces, materials, background, camera."""
+
+    def __init__(self, surfaces, materials, bg, camera):
+        self.surfaces = np.ascontiguousarray(surfaces, dtype=SURFACE)
+        self.materials = np.ascontiguousarray(materials, dtype=MATERIAL)
+        self.bg = np.ascontiguousarray(bg, dtype=np.float32)
+        self.camera = np.ascontiguousarray(camera, dtype=CAMERA).reshape(1)
+
+    @property
+    def width(self):
+        return int(self.camera["width"][0])
+
+    @property
+    def height(self):
+        return int(self.camera["height"][0])
+
+    @property
+    def n_triangles(self):
+        return int((self.surfaces["kind"] == TRIANGLE).sum())
+
+    @property
+    def n_spheres(self):
+        return int((self.surfaces["kind"] == SPHERE).sum())
+
+
+def builtin_scene(name, width, height):
+    """One of the reference's Scenes::* (src/scene.hpp:32-203) from the C++ host mirror,
+    flattened, with focal length = height as every built-in scene has."""
+    host = load_host()
+    surf = np.zeros(64, dtype=SURFACE)
+    mats = np.zeros(64, dtype=MATERIAL)
+    bg = np.zeros(3, dtype=np.float32)
+    cam = np.zeros(1, dtype=CAMERA)
+    n = C.c_int32(0)
+    rc = host.pt_host_builtin_scene(name.encode(), int(width), int(height), _p(surf), _p(mats),
+                                    C.c_int32(64), C.byref(n), _p(bg), _p(cam))
+    if rc != 0:
+        raise KeyError("unknown built-in scene %r" % name)
+    return SceneData(surf[:n.value].copy(), mats[:n.value].copy(), bg, cam)
+
+
+class Context:
+    """One GPU's render context (pt_ctx)."""
+
+    def __init__(self, device=0):
+        self._lib = load()
+        self._h = C.c_void_p()
+        rc = self._lib.pt_create(int(device), C.byref(self._h))
+        if rc != 0:
+            raise PtError(rc, self._lib.pt_global_error().decode())
+        self.width = self.height = 0
+
+    def close(self):
+        if self._h:
+            self._lib.pt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise PtError(rc, self._lib.pt_last_error(self._h).decode())
+
+    def set_stream(self, stream_ptr):
+        self._check(self._lib.pt_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def set_scene(self, surfaces, materials, bg):
+        surfaces = np.ascontiguousarray(surfaces, dtype=SURFACE)
+        materials = np.ascontiguousarray(materials, dtype=MATERIAL)
+        bg = np.ascontiguousarray(bg, dtype=np.float32)
+        self._check(self._lib.pt_set_scene(self._h, _p(surfaces), C.c_int32(len(surfaces)),
+                                           _p(materials), C.c_int32(len(materials)), _p(bg)))
+
+    def set_camera(self, camera):
+        camera = np.ascontiguousarray(camera, dtype=CAMERA).reshape(1)
+        self._check(self._lib.pt_set_camera(self._h, _p(camera)))
+        self.width = int(camera["width"][0])
+        self.height = int(camera["height"][0])
+
+    def load(self, scene):
+        """set_scene + set_camera from an object with surfaces/materials/bg/camera."""
+        self.set_scene(scene.surfaces, scene.materials, scene.bg)
+        self.set_camera(scene.camera)
+        return self
+
+    def clear(self):
+        self._check(self._lib.pt_clear(self._h))
+
+    def render(self, spp, first_sample=0, seed=1, mode=0):
+        self._check(self._lib.pt_render(self._h, C.c_uint32(spp), C.c_uint32(first_sample),
+                                        C.c_uint64(seed), C.c_int(mode)))
+
+    def render_into(self, device_ptr, spp, first_sample=0, seed=1, mode=0):
+        self._check(self._lib.pt_render_into(self._h, C.c_void_p(device_ptr), C.c_uint32(spp),
+                                             C.c_uint32(first_sample), C.c_uint64(seed),
+                                             C.c_int(mode)))
+
+    def read_accum(self):
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        total = C.c_uint64(0)
+        self._check(self._lib.pt_read_accum(self._h, _p(out), C.byref(total)))
+        return out, total.value
+
+    def write_accum(self, sums, total_samples):
+        sums = np.ascontiguousarray(sums, dtype=np.float32)
+        if sums.size != self.width * self.height * 3:
+            raise ValueError("sums must hold height*width*3 floats")
+        self._check(self._lib.pt_write_accum(self._h, _p(sums), C.c_uint64(total_samples)))
+
+    def tonemap_rgb8(self):
+        out = np.empty((self.height, self.width, 3), dtype=np.uint8)
+        self._check(self._lib.pt_tonemap_rgb8(self._h, _p(out)))
+        return out
+
+    def primary_hits(self):
+        idx = np.empty((self.height, self.width), dtype=np.int32)
+        dist = np.empty((self.height, self.width), dtype=np.float32)
+        self._check(self._lib.pt_primary_hits(self._h, _p(idx), _p(dist)))
+        return idx, dist
+
+    def intersect_rays(self, origin, direction):
+        origin = np.ascontiguousarray(origin, dtype=np.float32)
+        direction = np.ascontiguousarray(direction, dtype=np.float32)
+        n = origin.shape[0] if origin.ndim == 2 else 0
+        idx = np.empty(n, dtype=np.int32)
+        dist = np.empty(n, dtype=np.float32)
+        point = np.empty((n, 3), dtype=np.float32)
+        self._check(self._lib.pt_intersect_rays(self._h, _p(origin), _p(direction), C.c_int64(n),
+                                                _p(idx), _p(dist), _p(point)))
+        return idx, dist, point
+
+    def camera_rays(self, px, xi, numeric=NUM_EXACT):
+        px = np.ascontiguousarray(px, dtype=np.int32)
+        xi = np.ascontiguousarray(xi, dtype=np.float32)
+        n = px.shape[0]
+        origin = np.empty((n, 3), dtype=np.float32)
+        direction = np.empty((n, 3), dtype=np.float32)
+        self._check(self._lib.pt_camera_rays(self._h, _p(px), _p(xi), C.c_int64(n), _p(origin),
+                                             _p(direction), C.c_int(numeric)))
+        return origin, direction
+
+    def eval_bsdf(self, mtype, color, normal, incident, xi, numeric=NUM_EXACT):
+        mtype = np.ascontiguousarray(mtype, dtype=np.int32)
+        color = np.ascontiguousarray(color, dtype=np.float32)
+        normal = np.ascontiguousarray(normal, dtype=np.float32)
+        incident = np.ascontiguousarray(incident, dtype=np.float32)
+        xi = np.ascontiguousarray(xi, dtype=np.float32)
+        n = mtype.shape[0]
+        out_dir = np.empty((n, 3), dtype=np.float32)
+        out_brdf = np.empty((n, 3), dtype=np.float32)
+        self._check(self._lib.pt_eval_bsdf(self._h, _p(mtype), _p(color), _p(normal), _p(incident),
+                                           _p(xi), C.c_int64(n), _p(out_dir), _p(out_brdf),
+                                           C.c_int(numeric)))
+        return out_dir, out_brdf
+
+    def eval_brdf(self, mtype, color, normal, reflected):
+        mtype = np.ascontiguousarray(mtype, dtype=np.int32)
+        color = np.ascontiguousarray(color, dtype=np.float32)
+        normal = np.ascontiguousarray(normal, dtype=np.float32)
+        reflected = np.ascontiguousarray(reflected, dtype=np.float32)
+        n = mtype.shape[0]
+        out = np.empty((n, 3), dtype=np.float32)
+        self._check(self._lib.pt_eval_brdf(self._h, _p(mtype), _p(color), _p(normal), _p(reflected),
+                                           C.c_int64(n), _p(out)))
+        return out
+
+    def rng_uniform(self, seed, pixel, sample, draw):
+        pixel = np.ascontiguousarray(pixel, dtype=np.uint32)
+        sample = np.ascontiguousarray(sample, dtype=np.uint32)
+        draw = np.ascontiguousarray(draw, dtype=np.uint32)
+        out = np.empty(pixel.shape[0], dtype=np.float32)
+        self._check(self._lib.pt_rng_uniform(self._h, C.c_uint64(seed), _p(pixel), _p(sample),
+                                             _p(draw), C.c_int64(pixel.shape[0]), _p(out)))
+        return out
+
+    def counters(self):
+        c = Counters()
+        self._check(self._lib.pt_get_counters(self._h, C.byref(c)))
+        return c

@@ -1,0 +1,352 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU
+oracle on the same inputs and against the committed golden vectors.
+
+Bars: surface indices, hit distances, hit points and random variates are
+compared bit for bit (integer/index work and fp32 arithmetic restated
+operation by operation); sampler outputs and ray set-up within 1e-5 of a unit
+vector (the reference evaluates sin/cos/acos through libm, the device through
+its own routines); images statistically, against the oracle's noise floor.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+SCENES = ["dof_demo", "test", "orange_plane", "red_corner", "sunrise", "cornell_2", "cornell"]
+
+
+def load(ctx, scene):
+    ctx.set_scene(scene.surfaces, scene.materials, scene.bg)
+    ctx.set_camera(scene.camera)
+
+
+# ---------------------------------------------------------------- primary hits
+
+@pytest.mark.parametrize("name", SCENES)
+def test_primary_hits_bit_exact_vs_golden_800(ctx, pt, golden, name):
+    g = golden("primary_hits_800.npz")
+    load(ctx, pt.builtin_scene(name, 800, 800))
+    idx, dist = ctx.primary_hits()
+    want = g[name + "_idx"].astype(np.int32)
+    assert np.array_equal(idx, want), "%d of %d indices differ" % ((idx != want).sum(), idx.size)
+    assert np.array_equal(dist[::8, ::8], g[name + "_dist"])
+
+
+def test_survey_known_answers_on_gpu(ctx, pt):
+    with open(os.path.join(GOLDEN, "survey_known_answers.json")) as f:
+        kat = json.load(f)
+    for name, rows in kat.items():
+        if name == "note":
+            continue
+        load(ctx, pt.builtin_scene(name, 800, 800))
+        idx, dist = ctx.primary_hits()
+        for u, v, want_idx, want_dist in rows:
+            assert idx[v, u] == want_idx and dist[v, u] == np.float32(want_dist), (name, u, v)
+
+
+@pytest.mark.parametrize("name,w,h", [("cornell_2", 356, 200), ("orange_plane", 1600, 1600),
+                                      ("cornell", 333, 517), ("red_corner", 1, 1),
+                                      ("cornell_2", 3840, 2160)])
+def test_primary_hits_bit_exact_vs_oracle_other_sizes(ctx, pt, orc, name, w, h):
+    load(ctx, pt.builtin_scene(name, w, h))
+    idx, dist = ctx.primary_hits()
+    oidx, odist = orc.primary_hits(orc.builtin_scene(name, w, h))
+    assert np.array_equal(idx, oidx)
+    assert np.array_equal(dist, odist)
+
+
+# ---------------------------------------------------------------- closest hit on arbitrary rays
+
+def random_rays(rng, n, spread=3.0):
+    o = rng.uniform(-spread, spread, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    return o, d
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_intersect_rays_bit_exact(ctx, pt, orc, name):
+    rng = np.random.default_rng(11)
+    sc = pt.builtin_scene(name, 64, 64)
+    load(ctx, sc)
+    osc = orc.builtin_scene(name, 64, 64)
+    o, d = random_rays(rng, 200000)
+    # rays that start ON surfaces, as secondary rays do (no origin offset in the reference)
+    i0, _, p0 = orc.intersect_rays(osc, o[:50000], d[:50000])
+    hit = i0 >= 0
+    o[:50000][hit] = p0[hit]
+    # non-unit directions, as refracted rays can be
+    d[50000:60000] *= rng.uniform(0.5, 2.0, (10000, 1)).astype(np.float32)
+    idx, dist, point = ctx.intersect_rays(o, d)
+    oidx, odist, opoint = orc.intersect_rays(osc, o, d)
+    assert np.array_equal(idx, oidx), "%d indices differ" % (idx != oidx).sum()
+    assert np.array_equal(dist, odist)
+    assert np.array_equal(point, opoint)
+    assert (idx >= 0).sum() > 1000
+
+
+def test_intersect_edge_cases(ctx, pt, orc):
+    """Coincident surfaces (lowest index wins), grazing and degenerate rays, rays
+    parallel to a triangle, a ray starting inside a sphere, an empty batch."""
+    surf = np.zeros(5, dtype=pt.SURFACE)
+    surf["material"] = np.arange(5)
+    for i in (0, 1):                                   # two coincident triangles
+        surf[i]["kind"] = pt.TRIANGLE
+        surf[i]["a"], surf[i]["b"], surf[i]["c"] = (-1, -1, 2), (1, -1, 2), (0, 1, 2)
+    for i in (2, 3):                                   # two coincident spheres
+        surf[i]["kind"] = pt.SPHERE
+        surf[i]["a"], surf[i]["b"] = (5, 0, 0), (1, 0, 0)
+    surf[4]["kind"] = pt.TRIANGLE                      # degenerate (zero-area) triangle
+    surf[4]["a"], surf[4]["b"], surf[4]["c"] = (0, 0, 5), (1, 1, 5), (2, 2, 5)
+    mats = np.zeros(5, dtype=pt.MATERIAL)
+    ctx.set_scene(surf, mats, [0, 0, 0])
+    osc = orc.Scene(surf.view(orc.SURFACE), mats.view(orc.MATERIAL), [0, 0, 0],
+                    orc.camera_init([0, 0, 0], 0, 0, 8, 0, 8, 8))
+    o = np.float32([[0, 0, 0], [0, 0, 0], [5, 0, 0], [0, 0, 0], [0, -1, 0], [0, 0, 2], [0, 0, 0],
+                    [0, 0, 0], [5, 0, 3]])
+    d = np.float32([[0, 0, 1], [1, 0, 0], [0, 1, 0], [1, 0, 0.2], [0, 0, 1], [0, 0, 1], [0, 1, 0],
+                    [0, 0, 0], [0, 0, -1]])
+    idx, dist, point = ctx.intersect_rays(o, d)
+    oidx, odist, opoint = orc.intersect_rays(osc, o, d)
+    assert np.array_equal(idx, oidx) and np.array_equal(dist, odist, equal_nan=True)
+    assert np.array_equal(point, opoint, equal_nan=True)
+    assert idx[0] == 0 and idx[1] == 2 and idx[2] == 2      # ties go to the lower index
+    e = ctx.intersect_rays(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+    assert e[0].shape == (0,)
+
+
+def test_intersect_many_surfaces(ctx, pt, orc):
+    """A few thousand random triangles and spheres in one scene (ragged mix)."""
+    rng = np.random.default_rng(5)
+    n = 1365                                            # the LDS limit of this build
+    surf = np.zeros(n, dtype=pt.SURFACE)
+    surf["kind"] = rng.integers(0, 2, n)
+    surf["material"] = rng.integers(0, 7, n)
+    surf["a"] = rng.uniform(-4, 4, (n, 3))
+    surf["b"] = surf["a"] + rng.uniform(-0.7, 0.7, (n, 3))
+    surf["c"] = surf["a"] + rng.uniform(-0.7, 0.7, (n, 3))
+    sph = surf["kind"] == pt.SPHERE
+    surf["b"][sph, 0] = rng.uniform(0.05, 0.4, sph.sum())
+    mats = np.zeros(7, dtype=pt.MATERIAL)
+    ctx.set_scene(surf, mats, [0, 0, 0])
+    osc = orc.Scene(surf.view(orc.SURFACE), mats.view(orc.MATERIAL), [0, 0, 0],
+                    orc.camera_init([0, 0, 0], 0, 0, 8, 0, 8, 8))
+    o, d = random_rays(rng, 20000, 5.0)
+    idx, dist, point = ctx.intersect_rays(o, d)
+    oidx, odist, opoint = orc.intersect_rays(osc, o, d)
+    assert np.array_equal(idx, oidx) and np.array_equal(dist, odist) and np.array_equal(point, opoint)
+    assert len(np.unique(idx)) > 300
+    with pytest.raises(pt.PtError) as e:
+        big = np.zeros(n + 1, dtype=pt.SURFACE)
+        ctx.set_scene(big, mats, [0, 0, 0])
+    assert e.value.code == -4
+
+
+# ---------------------------------------------------------------- random numbers, ray set-up, materials
+
+def test_rng_bit_exact(ctx, orc):
+    with open(os.path.join(GOLDEN, "rng_table.json")) as f:
+        rows = json.load(f)
+    for seed in sorted({r[0] for r in rows}):
+        sub = [r for r in rows if r[0] == seed]
+        got = ctx.rng_uniform(seed, [r[1] for r in sub], [r[2] for r in sub], [r[3] for r in sub])
+        want = np.float32([float.fromhex(r[4]) for r in sub])
+        assert np.array_equal(got, want)
+    rng = np.random.default_rng(1)
+    px, sm, dr = (rng.integers(0, 2 ** 32, 5000, dtype=np.uint64).astype(np.uint32) for _ in range(3))
+    got = ctx.rng_uniform(77, px, sm, dr)
+    want = np.float32([orc.rng_uniform(77, int(a), int(b), int(c)) for a, b, c in zip(px, sm, dr)])
+    assert np.array_equal(got, want)
+    assert got.min() > 0 and got.max() < 1
+
+
+@pytest.mark.parametrize("numeric", ["exact", "fast"])
+def test_camera_rays(ctx, pt, golden, numeric):
+    """Ray set-up with forced random numbers: |delta| <= 1e-5 per component of the unit
+    direction, origin within 1e-5 relative to the aperture scale."""
+    g = golden("camera_rays.npz")
+    mode = pt.NUM_FAST if numeric == "fast" else pt.NUM_EXACT
+    for name in ("orange_plane", "cornell_2", "red_corner", "sunrise", "dof_demo"):
+        ctx.set_camera(g[name + "_camera"])
+        o, d = ctx.camera_rays(g[name + "_px"], g[name + "_xi"], mode)
+        assert np.abs(d - g[name + "_dir"]).max() <= 1e-5, name
+        assert np.abs(o - g[name + "_origin"]).max() <= 1e-5, name
+        if numeric == "exact" and not g[name + "_camera"]["dof_on"][0]:
+            assert np.array_equal(d, g[name + "_dir"]) and np.array_equal(o, g[name + "_origin"])
+
+
+@pytest.mark.parametrize("numeric", ["exact", "fast"])
+def test_bsdf_table(ctx, pt, golden, numeric):
+    """sample_pdf and brdf with forced random numbers: within 1e-5 (absolute, on unit
+    directions and on weights of magnitude <= 2)."""
+    g = golden("bsdf_table.npz")
+    mode = pt.NUM_FAST if numeric == "fast" else pt.NUM_EXACT
+    d, f = ctx.eval_bsdf(g["type"], g["color"], g["normal"], g["incident"], g["xi"], mode)
+    err_d = np.abs(d - g["out_dir"]).max(1)
+    err_f = np.abs(f - g["out_brdf"]).max(1)
+    for t, label in ((0, "diffuse"), (1, "mirror"), (2, "glass")):
+        m = g["type"] == t
+        print("%s %s: max dir err %.3g, max brdf err %.3g" % (numeric, label, err_d[m].max(), err_f[m].max()))
+    assert err_d.max() <= 1e-5
+    assert err_f.max() <= 2e-5
+    if numeric == "exact":
+        m = g["type"] != 0      # mirror and glass have no transcendental: bit-exact
+        assert np.array_equal(d[m], g["out_dir"][m]) and np.array_equal(f[m], g["out_brdf"][m])
+
+
+def test_brdf_alone(ctx, pt, golden):
+    g = golden("bsdf_table.npz")
+    f = ctx.eval_brdf(g["type"], g["color"], g["normal"], g["out_dir"])
+    assert np.array_equal(f, g["out_brdf"])
+
+
+# ---------------------------------------------------------------- the render step
+
+def render(ctx, pt, scene, spp, first=0, seed=1, mode=0):
+    load(ctx, scene)
+    ctx.render(spp, first, seed, mode)
+    acc, total = ctx.read_accum()
+    assert total == spp
+    return acc, ctx.counters()
+
+
+@pytest.mark.parametrize("name", ["cornell_2", "orange_plane", "red_corner", "cornell"])
+def test_render_paths_match_oracle(ctx, pt, orc, name):
+    """Same generator, same arithmetic: at a few samples per pixel almost every pixel of the
+    GPU image equals the oracle's to rounding.  The exceptions are paths where a
+    1-ulp difference in a sampled direction (device vs libm trigonometry) changes
+    which surface a later segment hits."""
+    w, h, spp = 96, 64, 4
+    acc, cnt = render(ctx, pt, pt.builtin_scene(name, w, h), spp, seed=9)
+    oacc, ocnt = orc.render(orc.builtin_scene(name, w, h), spp, seed=9, threads=8)
+    close = np.isclose(acc, oacc, rtol=2e-3, atol=2e-3).all(axis=2)
+    frac = close.mean()
+    print("%s: %.4f of pixels match; segments gpu %d oracle %d" % (name, frac, cnt.segments, ocnt.segments))
+    assert frac >= 0.97
+    assert cnt.samples == ocnt.samples == w * h * spp
+    assert abs(cnt.segments - ocnt.segments) <= 0.01 * ocnt.segments
+    assert cnt.tests == cnt.segments * len(pt.builtin_scene(name, w, h).surfaces)
+
+
+@pytest.mark.parametrize("numeric", ["exact", "fast"])
+@pytest.mark.parametrize("name", ["cornell_2", "orange_plane", "cornell"])
+def test_converged_image_rmse(ctx, pt, golden, name, numeric):
+    """4096 spp at 64x64 against the oracle's 4096-spp image.  Bound: the per-channel RMSE
+    between GPU and oracle (same seed) must not exceed 1.5x the oracle's own noise floor,
+    the RMSE between two oracle renders with different seeds."""
+    g = golden("render_64_4096spp.npz")
+    mode = pt.NUM_FAST if numeric == "fast" else pt.NUM_EXACT
+    acc, cnt = render(ctx, pt, pt.builtin_scene(name, 64, 64), 4096, seed=1, mode=mode)
+    mean = acc / 4096
+    ref, ref2 = g[name + "_mean"], g[name + "_mean_seed2"]
+    floor = np.sqrt(((ref - ref2) ** 2).mean((0, 1)))
+    rmse = np.sqrt(((mean - ref) ** 2).mean((0, 1)))
+    print("%s %s: rmse %s, noise floor %s" % (name, numeric, rmse, floor))
+    assert (rmse <= 1.5 * floor).all()
+    assert np.allclose(mean.mean((0, 1)), ref.mean((0, 1)), rtol=0.01)
+    assert abs(cnt.segments / cnt.samples - float(g[name + "_segments_per_sample"])) < 0.02
+
+
+def test_render_is_deterministic_and_ranges_add_up(ctx, pt):
+    """Bitwise repeatable; disjoint sample ranges sum to the one-range image up to fp32
+    addition order (the property the multi-GPU sample partition rests on)."""
+    sc = pt.builtin_scene("orange_plane", 128, 72)
+    a, _ = render(ctx, pt, sc, 24, seed=4)
+    b, _ = render(ctx, pt, sc, 24, seed=4)
+    assert np.array_equal(a, b)
+    load(ctx, sc)
+    for first, n in [(0, 10), (10, 7), (17, 7)]:
+        ctx.render(n, first, 4, 0)
+    parts, total = ctx.read_accum()
+    assert total == 24
+    assert np.allclose(parts, a, rtol=1e-5, atol=1e-5)
+    c, _ = render(ctx, pt, sc, 24, seed=5)
+    assert not np.array_equal(a, c)
+
+
+def test_render_accumulates_and_clears(ctx, pt):
+    sc = pt.builtin_scene("cornell_2", 64, 64)
+    load(ctx, sc)
+    ctx.render(3, 0, 1, 0)
+    ctx.render(2, 3, 1, 0)
+    acc, total = ctx.read_accum()
+    assert total == 5 and acc.sum() > 0
+    ctx.clear()
+    acc, total = ctx.read_accum()
+    assert total == 0 and not acc.any()
+    ctx.write_accum(np.full((64, 64, 3), 2.0, np.float32), 4)
+    acc, total = ctx.read_accum()
+    assert total == 4 and (acc == 2.0).all()
+
+
+def test_empty_scene_renders_background(ctx, pt):
+    cam = pt.builtin_scene("test", 40, 24).camera
+    ctx.set_scene(np.zeros(0, pt.SURFACE), np.zeros(0, pt.MATERIAL), [0.25, 0.5, 1.0])
+    ctx.set_camera(cam)
+    ctx.render(3, 0, 1, 0)
+    acc, _ = ctx.read_accum()
+    assert np.array_equal(acc, np.broadcast_to(np.float32([0.75, 1.5, 3.0]), acc.shape))
+    c = ctx.counters()
+    assert c.segments == c.samples == 40 * 24 * 3
+
+
+def test_render_into_external_device_buffer(ctx, pt):
+    import torch
+    sc = pt.builtin_scene("cornell_2", 80, 48)
+    a, _ = render(ctx, pt, sc, 6, seed=2)
+    buf = torch.zeros(48, 80, 3, dtype=torch.float32, device="cuda:0")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.render_into(buf.data_ptr(), 6, 0, 2, 0)
+    torch.cuda.synchronize()
+    ctx.set_stream(0)
+    assert np.array_equal(buf.cpu().numpy(), a)
+    with pytest.raises(pt.PtError):
+        ctx.render_into(0, 1, 0, 1, 0)
+
+
+def test_tonemap_matches_oracle(ctx, pt, orc):
+    sc = pt.builtin_scene("cornell_2", 64, 64)
+    acc, _ = render(ctx, pt, sc, 16, seed=1)
+    rgb = ctx.tonemap_rgb8()
+    want = orc.tonemap(acc, 16)
+    diff = np.abs(rgb.astype(int) - want.astype(int))
+    assert diff.max() <= 1            # powf may differ by an ulp across libm and the device
+    assert (diff == 0).mean() > 0.99
+
+
+def test_error_paths(pt):
+    c = pt.Context(0)
+    try:
+        with pytest.raises(pt.PtError):
+            c.render(1)                                   # no scene yet
+        sc = pt.builtin_scene("cornell_2", 32, 32)
+        c.set_scene(sc.surfaces, sc.materials, sc.bg)
+        with pytest.raises(pt.PtError):
+            c.render(1)                                   # no camera yet
+        c.set_camera(sc.camera)
+        with pytest.raises(pt.PtError):
+            c.render(0)                                   # zero samples
+        with pytest.raises(pt.PtError):
+            c.render(1, 0, 1, 0x40)                       # unknown mode bit
+        bad = sc.surfaces.copy()
+        bad["material"][0] = 99
+        with pytest.raises(pt.PtError):
+            c.set_scene(bad, sc.materials, sc.bg)
+        bad = sc.surfaces.copy()
+        bad["kind"][0] = 7
+        with pytest.raises(pt.PtError):
+            c.set_scene(bad, sc.materials, sc.bg)
+        cam = sc.camera.copy()
+        cam["width"] = 0
+        with pytest.raises(pt.PtError):
+            c.set_camera(cam)
+        c.render(1)                                       # still usable after errors
+    finally:
+        c.close()
+    with pytest.raises(pt.PtError):
+        pt.Context(4096)
