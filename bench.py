@@ -161,6 +161,7 @@ def main():
                          "flops_per_launch": sum(flops) / len(flops)},
             "tests_per_s": sum(segments) / len(segments) * n_surf / (avg_ms * 1e-3),
             "segments_per_sample": sum(segments) / len(segments) / (width * height * args.spp),
+            "redone_per_segment": c.redone / max(c.segments, 1),
             "vgprs": int(c.vgprs),
             "grid_blocks": int(c.grid_blocks),
         }

@@ -80,6 +80,7 @@ typedef struct pt_counters {
     uint64_t samples;          /* paths traced by the last pt_render */
     uint64_t segments;         /* closest-hit queries (src/main.cpp:85) in the last pt_render */
     uint64_t tests;            /* segments x surfaces */
+    uint64_t redone;           /* segments whose closest hit was re-evaluated with IEEE divisions */
     double kernel_ms;          /* device time of the last pt_render's render kernel (HIP events) */
     double total_ms;           /* the same including the partial-sum reduction */
     double flops;              /* algorithmic flops: segments x (63 n_tri + 18 n_sph) */

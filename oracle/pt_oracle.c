@@ -382,7 +382,7 @@ static inline uint32_t pcg(uint32_t v)
     return (w >> 22) ^ w;
 }
 
-typedef struct { uint32_t k0, k1, ctr; } rng_t;
+typedef struct { uint32_t key, ctr; } rng_t;
 
 static inline uint32_t seed_mix(uint64_t seed)
 {
@@ -392,15 +392,14 @@ static inline uint32_t seed_mix(uint64_t seed)
 static inline rng_t rng_path(uint32_t smix, uint32_t pixel, uint32_t sample)
 {
     rng_t r;
-    r.k0 = pcg(pcg(smix ^ pixel) + sample);
-    r.k1 = pcg(pcg(~smix ^ sample) + pixel);
+    r.key = pcg(pcg(smix ^ pixel) + sample);
     r.ctr = 0;
     return r;
 }
 
 static inline float rng_at(const rng_t *r, uint32_t draw)
 {
-    uint32_t x = pcg(r->k0 + draw) ^ r->k1;
+    uint32_t x = pcg(r->key + draw);
     return (float)((x >> 8) | 1u) * 0x1p-24f;    /* odd/2^24: in (0,1), exact */
 }
 

@@ -63,7 +63,7 @@ struct pt_ctx {
 
     float *d_slabs = nullptr;        // partial sums of the work items
     size_t slab_floats = 0;
-    uint32_t *d_queue = nullptr;     // [0] work counter; 8 bytes further: the segment counter
+    uint32_t *d_queue = nullptr;     // [0] work counter; [2..3], [4..5]: 64-bit segment and redo counters
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 
     int num_cus = 0;
@@ -185,7 +185,7 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
     P.queue_head = ctx->d_queue;
     P.stats = reinterpret_cast<unsigned long long *>(ctx->d_queue + 2);
 
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 16, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 32, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     hipLaunchKernelGGL(k_render_mega<FAST>, dim3(grid), dim3(BLOCK), lds_bytes, ctx->stream, P);
     HIP_TRY(ctx, hipGetLastError());
@@ -242,7 +242,7 @@ int pt_create(int device, pt_ctx **out)
         delete ctx;
         return fail(nullptr, PT_E_HIP, "device %d is %s; this library holds gfx950 code only", device, prop.gcnArchName);
     }
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_queue, 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_queue, 32);
     for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipEventCreate(&ctx->ev[i]);
     if (e != hipSuccess) {
         int rc = fail(nullptr, PT_E_HIP, "pt_create on device %d: %s", device, hipGetErrorString(e));
@@ -629,9 +629,11 @@ int pt_get_counters(pt_ctx *ctx, pt_counters *out)
         float ms_kernel = 0, ms_total = 0;
         HIP_TRY(ctx, hipEventElapsedTime(&ms_kernel, ctx->ev[0], ctx->ev[1]));
         HIP_TRY(ctx, hipEventElapsedTime(&ms_total, ctx->ev[0], ctx->ev[2]));
-        unsigned long long seg = 0;
-        HIP_TRY(ctx, hipMemcpy(&seg, ctx->d_queue + 2, 8, hipMemcpyDeviceToHost));
+        unsigned long long st[2] = {0, 0};
+        HIP_TRY(ctx, hipMemcpy(st, ctx->d_queue + 2, 16, hipMemcpyDeviceToHost));
+        const unsigned long long seg = st[0];
         ctx->last.segments = seg;
+        ctx->last.redone = st[1];
         ctx->last.tests = seg * (uint64_t)ctx->n_surfaces;
         ctx->last.kernel_ms = ms_kernel;
         ctx->last.total_ms = ms_total;

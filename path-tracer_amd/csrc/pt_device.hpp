@@ -107,20 +107,22 @@ PT_DEV uint32_t pcg(uint32_t v)
     return (w >> 22) ^ w;
 }
 
-struct Rng { uint32_t k0, k1, ctr; };
+struct Rng { uint32_t key, ctr; };
 
-PT_DEV Rng rng_path(uint32_t seed_mix, uint32_t pixel, uint32_t sample)
+// Per-pixel part of the key: computed once per work item.
+PT_DEV uint32_t rng_pixel(uint32_t seed_mix, uint32_t pixel) { return pcg(seed_mix ^ pixel); }
+
+PT_DEV Rng rng_path(uint32_t pixel_key, uint32_t sample)
 {
     Rng r;
-    r.k0 = pcg(pcg(seed_mix ^ pixel) + sample);
-    r.k1 = pcg(pcg(~seed_mix ^ sample) + pixel);
+    r.key = pcg(pixel_key + sample);
     r.ctr = 0;
     return r;
 }
 
 PT_DEV float rng_at(const Rng &r, uint32_t draw)
 {
-    uint32_t x = pcg(r.k0 + draw) ^ r.k1;
+    const uint32_t x = pcg(r.key + draw);
     return (float)((x >> 8) | 1u) * 0x1p-24f;
 }
 
@@ -209,63 +211,91 @@ struct Hit { int idx; float t; float dist; };
 // -EPSILON < x <=> x >= -1e-5f.
 constexpr float EPS_F = 1e-5f;
 
-// Triangle::intersects, src/surface.hpp:47-73.  g = the surface's geometry
-// record (wave-uniform).  nd = -ray_dir.  Returns true on a hit and sets t and
-// distance = length(t*ray_dir).
+// The four determinants of Triangle::intersects (src/surface.hpp:51-65) in
+// GLM's expansion, sharing the minors that recur (each shared value is the
+// same sequence of roundings wherever the reference computes it):
+//   det_a = determinant(-d, e1, e2)   du = determinant(-d, b, e2)
+//   dv    = determinant(-d, e1, b)    dt = determinant(b, e1, e2)
+struct TriDets { float det_a, du, dv, dt; };
+
 template <bool FAST>
-PT_DEV bool triangle_test(cfloat_p g, V3 o, V3 d, V3 nd, float &t_out, float &dist_out)
+PT_DEV TriDets triangle_dets(cfloat_p g, V3 o, V3 nd)
 {
     using N = Num<FAST>;
     const V3 v0 = v3(g[0], g[1], g[2]);
     const V3 e1 = v3(g[4], g[5], g[6]);
     const V3 e2 = v3(g[8], g[9], g[10]);
-    const float m_e = g[7];                    // e1.y*e2.z - e2.y*e1.z
+    const float m_e = g[7];                              // e1.y*e2.z - e2.y*e1.z
+    const V3 b = o - v0;                                 // :56
+    const float m_de2 = N::msub(nd.y, e2.z, e2.y, nd.z);
+    const float m_de1 = N::msub(nd.y, e1.z, e1.y, nd.z);
+    const float m_be2 = N::msub(b.y, e2.z, e2.y, b.z);
+    const float m_db = N::msub(nd.y, b.z, b.y, nd.z);
+    const float m_e1b = N::msub(e1.y, b.z, b.y, e1.z);
+    const float m_be1 = N::msub(b.y, e1.z, e1.y, b.z);
+    TriDets r;
+    if constexpr (FAST) {
+        r.det_a = __builtin_fmaf(e2.x, m_de1, __builtin_fmaf(nd.x, m_e, -(e1.x * m_de2)));
+        r.du = __builtin_fmaf(e2.x, m_db, __builtin_fmaf(nd.x, m_be2, -(b.x * m_de2)));
+        r.dv = __builtin_fmaf(b.x, m_de1, __builtin_fmaf(nd.x, m_e1b, -(e1.x * m_db)));
+        r.dt = __builtin_fmaf(e2.x, m_be1, __builtin_fmaf(b.x, m_e, -(e1.x * m_be2)));
+    } else {
+        r.det_a = nd.x * m_e - e1.x * m_de2 + e2.x * m_de1;
+        r.du = nd.x * m_be2 - b.x * m_de2 + e2.x * m_db;
+        r.dv = nd.x * m_e1b - e1.x * m_db + b.x * m_de1;
+        r.dt = b.x * m_e - e1.x * m_be2 + e2.x * m_be1;
+    }
+    return r;
+}
 
-    // determinant(mat3(-d, e1, e2))
-    const float m1a = N::msub(nd.y, e2.z, e2.y, nd.z);
-    const float m2a = N::msub(nd.y, e1.z, e1.y, nd.z);
-    float det_a;
-    if constexpr (FAST) det_a = __builtin_fmaf(e2.x, m2a, __builtin_fmaf(nd.x, m_e, -(e1.x * m1a)));
-    else det_a = nd.x * m_e - e1.x * m1a + e2.x * m2a;
-    bool ok = !(det_a >= -EPS_F && det_a <= EPS_F);                 // :53
-
-    const V3 b = o - v0;                                            // :56
-    const float u = N::div(N::det(nd, b, e2), det_a);               // :57
+// Triangle::intersects, src/surface.hpp:47-73, evaluated directly: IEEE
+// quotients in EXACT.  Returns true on a hit; t, distance = length(t*ray_dir).
+template <bool FAST>
+PT_DEV bool triangle_direct(cfloat_p g, V3 o, V3 d, V3 nd, float &t_out, float &dist_out)
+{
+    using N = Num<FAST>;
+    const TriDets q = triangle_dets<FAST>(g, o, nd);
+    bool ok = !(q.det_a >= -EPS_F && q.det_a <= EPS_F);             // :53
+    const float u = N::div(q.du, q.det_a);                          // :57
     ok = ok && !(u < -EPS_F || u >= 1.0f);                          // :58
-
-    const float v = N::div(N::det(nd, e1, b), det_a);               // :61
+    const float v = N::div(q.dv, q.det_a);                          // :61
     ok = ok && !(v < -EPS_F || u + v >= 1.0f);                      // :62
-
-    // determinant(mat3(b, e1, e2))
-    const float m1t = N::msub(b.y, e2.z, e2.y, b.z);
-    const float m2t = N::msub(b.y, e1.z, e1.y, b.z);
-    float det_t;
-    if constexpr (FAST) det_t = __builtin_fmaf(e2.x, m2t, __builtin_fmaf(b.x, m_e, -(e1.x * m1t)));
-    else det_t = b.x * m_e - e1.x * m1t + e2.x * m2t;
-    const float t = N::div(det_t, det_a);                           // :65
+    const float t = N::div(q.dt, q.det_a);                          // :65
     ok = ok && !(t <= EPS_F);                                       // :66
-
     const V3 td = d * t;                                            // :70
     t_out = t;
     dist_out = N::sqrt(N::dot(td, td));
     return ok;
 }
 
-// Sphere::intersects, src/surface.hpp:91-112.
+// The part of Sphere::intersects (src/surface.hpp:91-101) before the square
+// root: tca, and arg = radius2 - d2.  pre_ok is false when the reference has
+// already returned (tca < 0 or d2 > radius2).
 template <bool FAST>
-PT_DEV bool sphere_test(cfloat_p g, V3 o, V3 d, float &t_out, float &dist_out)
+PT_DEV bool sphere_pre(cfloat_p g, V3 o, V3 d, float &tca, float &arg)
 {
     using N = Num<FAST>;
     const V3 c = v3(g[0], g[1], g[2]);
     const float radius2 = g[4];
     const V3 L = c - o;
-    const float tca = N::dot(L, d);
+    tca = N::dot(L, d);
     bool ok = !(tca < 0.0f);                                        // :94
     float d2;
     if constexpr (FAST) d2 = __builtin_fmaf(-tca, tca, N::dot(L, L));
     else d2 = N::dot(L, L) - tca * tca;                             // :97
     ok = ok && !(d2 > radius2);                                     // :98
-    const float thc = N::sqrt(radius2 - d2);                        // :101
+    arg = radius2 - d2;
+    return ok;
+}
+
+// Sphere::intersects, src/surface.hpp:91-112, evaluated directly.
+template <bool FAST>
+PT_DEV bool sphere_direct(cfloat_p g, V3 o, V3 d, float &t_out, float &dist_out)
+{
+    using N = Num<FAST>;
+    float tca, arg;
+    bool ok = sphere_pre<FAST>(g, o, d, tca, arg);
+    const float thc = N::sqrt(arg);                                 // :101
     float t = tca - thc;                                            // :103
     if (t <= EPS_F) {                                               // :105
         t = tca + thc;
@@ -276,10 +306,10 @@ PT_DEV bool sphere_test(cfloat_p g, V3 o, V3 d, float &t_out, float &dist_out)
     return ok;
 }
 
-// closest_intersection, src/main.cpp:56-67: scene order, a later surface
-// replaces the current one only when strictly closer.
+// closest_intersection, src/main.cpp:56-67, evaluated directly: scene order,
+// a later surface replaces the current one only when strictly closer.
 template <bool FAST>
-PT_DEV Hit closest_intersection(cfloat_p geom, int n_surfaces, V3 o, V3 d)
+PT_DEV Hit closest_direct(cfloat_p geom, int n_surfaces, V3 o, V3 d)
 {
     Hit best;
     best.idx = -1;
@@ -291,9 +321,9 @@ PT_DEV Hit closest_intersection(cfloat_p geom, int n_surfaces, V3 o, V3 d)
         float t, dist;
         bool ok;
         if (__builtin_bit_cast(int, g[3]) == 0)      // wave-uniform branch
-            ok = triangle_test<FAST>(g, o, d, nd, t, dist);
+            ok = triangle_direct<FAST>(g, o, d, nd, t, dist);
         else
-            ok = sphere_test<FAST>(g, o, d, t, dist);
+            ok = sphere_direct<FAST>(g, o, d, t, dist);
         if (ok && (best.idx < 0 || dist < best.dist)) {
             best.idx = i;
             best.t = t;
@@ -301,6 +331,145 @@ PT_DEV Hit closest_intersection(cfloat_p geom, int n_surfaces, V3 o, V3 d)
         }
     }
     return best;
+}
+
+// ---- filtered evaluation ----------------------------------------------------
+//
+// The direct form spends most of its instructions on three correctly rounded
+// divisions and a square root per triangle (a square root per sphere), whose
+// results are only compared against thresholds and against each other.  The
+// filtered form computes the same numerators and denominators, in the same
+// arithmetic, but replaces each quotient by numerator * v_rcp(denominator) and
+// each root by v_sqrt (both within 1 ulp), and takes a decision from such an
+// approximation only when it lies outside an error band round the threshold
+// that is several times wider than the approximation's worst error.  A lane
+// with any value inside a band, or two candidate distances closer than their
+// error bounds, or a NaN, is re-evaluated by closest_direct; that happens for
+// about one ray in 10^5.  The winner's t (and distance) is then computed once,
+// with the reference's correctly rounded operations, from the exact numerator
+// and denominator kept for it.  The result is identical to closest_direct's;
+// the bit-exact parity tests run through this function.
+//
+// Error budget (relative, fp32): quotient' = n * rcp(d): 2^-23 + 2^-24 ~ 1.8e-7,
+// plus the exact quotient's own 6e-8.  Bands: 1e-5 relative round +-EPSILON,
+// 2e-6 absolute round 1 (u and v are at most about 1 there), 2e-6 relative on
+// triangle distances (which also covers |d|' and the reference's roundings of
+// length(t*d)), 4e-7 * (thc + |t|) absolute on sphere distances (v_sqrt's 1 ulp
+// against the correctly rounded root, and one rounding of tca -+ thc).
+
+constexpr float BAND_LO_REJ = -1.00001e-5f, BAND_LO_ACC = -0.99999e-5f;   // round -EPSILON
+constexpr float BAND_T_REJ = 0.99999e-5f, BAND_T_ACC = 1.00001e-5f;       // round +EPSILON
+constexpr float BAND_ONE_REJ = 1.0f + 2e-6f, BAND_ONE_ACC = 1.0f - 2e-6f; // round 1
+constexpr float TRI_DIST_ERR = 2e-6f, SPH_DIST_ERR = 4e-7f;
+
+// Best candidate so far: approximate distance with an absolute error bound, and
+// the exact operands of the final evaluation.  mode 0: triangle, t = a / b;
+// mode 1: sphere, t = a - sqrt(b); mode 2: sphere, t = a + sqrt(b).
+struct Best { int idx; int mode; float dist, err, a, b; };
+
+template <bool FAST, bool NEED_DIST>
+PT_DEV Hit closest_intersection(cfloat_p geom, int n_surfaces, V3 o, V3 d,
+                                unsigned long long *redo_count = nullptr)
+{
+    using N = Num<FAST>;
+    Best best = {-1, 0, 0.0f, 0.0f, 0.0f, 0.0f};
+    bool unsure = false;
+    const V3 nd = -d;
+    const float len_d = __builtin_amdgcn_sqrtf(N::dot(d, d));
+    for (int i = 0; i < n_surfaces; i++) {
+        cfloat_p g = geom + (size_t)i * GEOM_STRIDE;
+        bool acc;           // surely a hit (FAST: a hit)
+        bool rej;           // surely not a hit
+        int mode;
+        float dist, err, a, b;
+        if (__builtin_bit_cast(int, g[3]) == 0) {    // wave-uniform branch
+            const TriDets q = triangle_dets<FAST>(g, o, nd);
+            const float inv = __builtin_amdgcn_rcpf(q.det_a);
+            const float u = q.du * inv, v = q.dv * inv, t = q.dt * inv;
+            const float s = u + v;
+            const bool det_bad = q.det_a >= -EPS_F && q.det_a <= EPS_F;
+            if constexpr (FAST) {
+                acc = !(det_bad | (u < -EPS_F) | (u >= 1.0f) | (v < -EPS_F) | (s >= 1.0f) | (t <= EPS_F));
+                rej = !acc;
+            } else {
+                // non-short-circuit on purpose: every comparison is one instruction
+                rej = det_bad | (u < BAND_LO_REJ) | (u > BAND_ONE_REJ) | (v < BAND_LO_REJ) |
+                      (s > BAND_ONE_REJ) | (t < BAND_T_REJ);
+                acc = !det_bad & (u > BAND_LO_ACC) & (u < BAND_ONE_ACC) & (v > BAND_LO_ACC) &
+                      (s < BAND_ONE_ACC) & (t > BAND_T_ACC);
+            }
+            mode = 0;
+            a = q.dt;
+            b = q.det_a;
+            dist = t * len_d;
+            err = dist * TRI_DIST_ERR;
+        } else {
+            float tca, arg;
+            const bool pre_ok = sphere_pre<FAST>(g, o, d, tca, arg);
+            const float thc = __builtin_amdgcn_sqrtf(arg);
+            const float t1 = tca - thc, t2 = tca + thc;
+            if constexpr (FAST) {
+                const bool near = !(t1 <= EPS_F);
+                dist = near ? t1 : t2;
+                acc = pre_ok & !(dist <= EPS_F);
+                rej = !acc;
+                mode = near ? 1 : 2;
+                err = 0.0f;
+            } else {
+                const float e1 = SPH_DIST_ERR * (thc + __builtin_fabsf(t1));
+                const float e2 = SPH_DIST_ERR * (thc + __builtin_fabsf(t2));
+                const bool near_ok = t1 - e1 > BAND_T_ACC, near_bad = t1 + e1 < BAND_T_REJ;
+                const bool far_ok = t2 - e2 > BAND_T_ACC, far_bad = t2 + e2 < BAND_T_REJ;
+                acc = pre_ok & (near_ok | (near_bad & far_ok));
+                rej = !pre_ok | (near_bad & far_bad);
+                dist = near_ok ? t1 : t2;
+                err = near_ok ? e1 : e2;
+                mode = near_ok ? 1 : 2;
+            }
+            a = tca;
+            b = arg;
+        }
+        if constexpr (FAST) {
+            if (acc & ((best.idx < 0) | (dist < best.dist))) best = {i, mode, dist, 0.0f, a, b};
+        } else {
+            // src/main.cpp:61: replace only when strictly closer
+            const bool closer = (best.idx < 0) | (dist + err < best.dist - best.err);
+            const bool not_closer = dist - err > best.dist + best.err;
+            unsure = unsure | !(acc | rej) | (acc & !(closer | not_closer));
+            if (acc & closer) best = {i, mode, dist, err, a, b};
+        }
+    }
+
+    Hit h;
+    h.idx = best.idx;
+    h.t = 0.0f;
+    h.dist = 0.0f;
+    if constexpr (FAST) {
+        h.t = best.mode == 0 ? best.a * __builtin_amdgcn_rcpf(best.b) : best.dist;
+        h.dist = best.dist;
+        return h;
+    } else {
+        if (__any(unsure)) {                         // rare: redo those lanes directly
+            if (unsure) {
+                if (redo_count) atomicAdd(redo_count, 1ull);
+                return closest_direct<false>(geom, n_surfaces, o, d);
+            }
+        }
+        if (best.idx >= 0) {
+            if (best.mode == 0) {
+                h.t = best.a / best.b;                              // surface.hpp:65
+                if constexpr (NEED_DIST) {
+                    const V3 td = d * h.t;                          // surface.hpp:70
+                    h.dist = __builtin_sqrtf(N::dot(td, td));
+                }
+            } else {
+                const float thc = __builtin_sqrtf(best.b);          // surface.hpp:101
+                h.t = best.mode == 1 ? best.a - thc : best.a + thc;
+                h.dist = h.t;                                       // surface.hpp:111
+            }
+        }
+        return h;
+    }
 }
 
 // ---------------------------------------------------------------- materials

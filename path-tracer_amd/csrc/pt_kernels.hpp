@@ -24,7 +24,7 @@ struct RenderParams {
     uint32_t n_items;         // n_pixels * ceil(spp / chunk_len); item = chunk * n_pixels + pixel
     float *slabs;             // n_items * 3 partial sums, slab of chunk k at k * n_pixels * 3
     uint32_t *queue_head;     // zeroed before the launch
-    unsigned long long *stats;  // [0] += segments
+    unsigned long long *stats;  // [0] += segments, [1] += segments re-evaluated directly
 };
 
 // ---------------------------------------------------------------- parity kernels
@@ -39,7 +39,7 @@ k_primary_hits(Camera cam, const float *geom_g, int n_surfaces, int32_t *idx, fl
     const int x = p % cam.width, y = p / cam.width;
     const V3 o = v3(cam.pos[0], cam.pos[1], cam.pos[2]);
     const V3 d = ray_direction_by_pixel<FAST>(cam, (float)x, (float)y);
-    const Hit h = closest_intersection<FAST>(as_constant(geom_g), n_surfaces, o, d);
+    const Hit h = closest_intersection<FAST, true>(as_constant(geom_g), n_surfaces, o, d);
     idx[p] = h.idx;
     dist[p] = h.idx < 0 ? 0.0f : h.dist;
 }
@@ -53,7 +53,7 @@ k_intersect_rays(const float *geom_g, int n_surfaces, const float *org, const fl
     if (i >= n) return;
     const V3 o = v3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
     const V3 d = v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
-    const Hit h = closest_intersection<FAST>(as_constant(geom_g), n_surfaces, o, d);
+    const Hit h = closest_intersection<FAST, true>(as_constant(geom_g), n_surfaces, o, d);
     idx[i] = h.idx;
     dist[i] = h.idx < 0 ? 0.0f : h.dist;
     V3 pt = v3(0, 0, 0);
@@ -109,7 +109,7 @@ k_rng_uniform(uint32_t seed_mix, const uint32_t *pixel, const uint32_t *sample,
 {
     const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    const Rng r = rng_path(seed_mix, pixel[i], sample[i]);
+    const Rng r = rng_path(rng_pixel(seed_mix, pixel[i]), sample[i]);
     out[i] = rng_at(r, draw[i]);
 }
 
@@ -126,7 +126,16 @@ template <bool FAST>
 __global__ void __launch_bounds__(BLOCK)
 k_render_mega(RenderParams P)
 {
+    // FAST selects the arithmetic of the closest-hit search (and of the hit
+    // point): EXACT finds, for every ray, the surface and parameter t the
+    // reference's arithmetic finds.  Quantities that are continuous functions
+    // of random numbers - the jittered camera ray, sphere normals, sampled
+    // directions, throughput - use fused multiply-adds and the hardware
+    // reciprocal/root/sine (each within 1 ulp) in both modes: the reference
+    // evaluates them through libm in double, which no fp32 path matches bit
+    // for bit, and they are checked to 1e-5 instead.
     using N = Num<FAST>;
+    using S = Num<true>;
     extern __shared__ __align__(16) float lds_shade[];
     for (int i = threadIdx.x; i < P.n_surfaces * SHADE_STRIDE; i += BLOCK)
         lds_shade[i] = P.shade[i];
@@ -141,11 +150,11 @@ k_render_mega(RenderParams P)
     bool drained = false;
 
     bool have_item = false, need_path = true;
-    uint32_t item = 0, pixel = 0, s = 0, s_end = 0;
+    uint32_t item = 0, pixel = 0, pixel_key = 0, s = 0, s_end = 0;
     int px = 0, py = 0, depth = 0;
     V3 sum = v3(0, 0, 0), col = v3(0, 0, 0), thr = v3(1, 1, 1);
     V3 o = v3(0, 0, 0), d = v3(0, 0, 1);
-    Rng rng = {0, 0, 0};
+    Rng rng = {0, 0};
     unsigned long long n_seg = 0;
 
     for (;;) {
@@ -192,14 +201,15 @@ k_render_mega(RenderParams P)
                 const uint32_t last = P.first_sample + P.spp;
                 s_end = s + P.chunk_len < last ? s + P.chunk_len : last;
                 sum = v3(0, 0, 0);
+                pixel_key = rng_pixel(P.seed_mix, pixel);
             }
         }
         if (need_path) {                        // trace_rays' per-pixel set-up, main.cpp:120-136
-            rng = rng_path(P.seed_mix, pixel, s);
+            rng = rng_path(pixel_key, s);
             const float xu = rng_next(rng), xv = rng_next(rng);
             float xr = 0.0f, xp = 0.0f;
             if (P.cam.dof_on) { xr = rng_next(rng); xp = rng_next(rng); }
-            camera_ray<FAST>(P.cam, px, py, xu, xv, xr, xp, o, d);
+            camera_ray<true>(P.cam, px, py, xu, xv, xr, xp, o, d);
             col = v3(0, 0, 0);
             thr = v3(1, 1, 1);
             depth = 0;
@@ -207,12 +217,12 @@ k_render_mega(RenderParams P)
         }
 
         // one iteration of trace_ray's loop, main.cpp:84-109
-        const Hit h = closest_intersection<FAST>(geom, P.n_surfaces, o, d);
+        const Hit h = closest_intersection<FAST, false>(geom, P.n_surfaces, o, d, P.stats + 1);
         n_seg++;
         bool ended;
         if (h.idx < 0) {
-            col = v3(N::mad(P.bg[0], thr.x, col.x), N::mad(P.bg[1], thr.y, col.y),
-                     N::mad(P.bg[2], thr.z, col.z));
+            col = v3(S::mad(P.bg[0], thr.x, col.x), S::mad(P.bg[1], thr.y, col.y),
+                     S::mad(P.bg[2], thr.z, col.z));
             ended = true;
         } else {
             const float4 r0 = *reinterpret_cast<const float4 *>(lds_shade + h.idx * SHADE_STRIDE);
@@ -222,14 +232,14 @@ k_render_mega(RenderParams P)
             const int type = flags & 0xff;
             const V3 point = N::along(o, d, h.t);
             V3 normal = v3(r2.x, r2.y, r2.z);
-            if (flags >> 8) normal = N::normalize(point - normal);   // sphere, surface.hpp:86-88
+            if (flags >> 8) normal = S::normalize(point - normal);   // sphere, surface.hpp:86-88
             float xi0 = 0.0f, xi1 = 0.0f;
             if (type == 0) { xi0 = rng_next(rng); xi1 = rng_next(rng); }
             else if (type == 2) { xi0 = rng_next(rng); }
-            const V3 new_dir = sample_pdf<FAST>(type, normal, d, xi0, xi1);
+            const V3 new_dir = sample_pdf<true>(type, normal, d, xi0, xi1);
             o = point;
-            col = v3(N::mad(r1.x, thr.x, col.x), N::mad(r1.y, thr.y, col.y), N::mad(r1.z, thr.z, col.z));
-            thr = thr * brdf<FAST>(type, v3(r0.x, r0.y, r0.z), normal, new_dir);
+            col = v3(S::mad(r1.x, thr.x, col.x), S::mad(r1.y, thr.y, col.y), S::mad(r1.z, thr.z, col.z));
+            thr = thr * brdf<true>(type, v3(r0.x, r0.y, r0.z), normal, new_dir);
             d = new_dir;
             ended = false;
             if (depth >= 5) {                   // russian roulette, main.cpp:97-104
@@ -240,7 +250,7 @@ k_render_mega(RenderParams P)
                     m = thr.x < m ? m : thr.x;
                     const float p = m < 0.0f ? 0.0f : (0.95f < m ? 0.95f : m);
                     if (rng_next(rng) > p) ended = true;
-                    else thr = thr * N::div(1.0f, p);
+                    else thr = thr * S::div(1.0f, p);
                 }
             }
             depth++;

@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpt_amd.so")
+# PT_AMD_LIB selects another build of the same library (A/B experiments).
+LIB_PATH = os.environ.get("PT_AMD_LIB") or os.path.join(_HERE, "lib", "libpt_amd.so")
 HOST_LIB_PATH = os.path.join(_HERE, "lib", "libpt_host.so")
 
 SURFACE = np.dtype([("kind", "<i4"), ("material", "<i4"), ("a", "<f4", 3),
@@ -39,6 +40,7 @@ ABI_SYMBOLS = (
 
 class Counters(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("tests", C.c_uint64),
+                ("redone", C.c_uint64),
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("flops", C.c_double),
                 ("vgprs", C.c_uint32), ("grid_blocks", C.c_uint32)]
 

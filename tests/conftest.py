@@ -39,6 +39,12 @@ def golden():
 @pytest.fixture(scope="session")
 def ctx(pt):
     """One GPU context shared by the GPU tests (a single process on the card)."""
+    # PyTorch-ROCm bundles its own HIP runtime: when a process uses both, torch
+    # has to initialise first, or it finds no GPU once another copy of the
+    # runtime holds the device.
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
     c = pt.Context(0)
     yield c
     c.close()
