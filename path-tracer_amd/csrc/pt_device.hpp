@@ -362,17 +362,19 @@ constexpr float BAND_T_REJ = 0.99999e-5f, BAND_T_ACC = 1.00001e-5f;       // rou
 constexpr float BAND_ONE_REJ = 1.0f + 2e-6f, BAND_ONE_ACC = 1.0f - 2e-6f; // round 1
 constexpr float TRI_DIST_ERR = 2e-6f, SPH_DIST_ERR = 4e-7f;
 
-// Best candidate so far: approximate distance with an absolute error bound, and
-// the exact operands of the final evaluation.  mode 0: triangle, t = a / b;
-// mode 1: sphere, t = a - sqrt(b); mode 2: sphere, t = a + sqrt(b).
-struct Best { int idx; int mode; float dist, err, a, b; };
+// Best candidate so far.  [lo, hi] brackets its exact distance; a and b are the
+// exact operands of the final evaluation; code = 4 * surface index + mode, with
+// mode 0: triangle, t = a / b;  mode 1: sphere, t = a - sqrt(b);  mode 2:
+// sphere, t = a + sqrt(b).  code < 0: no hit yet.
+struct Best { int code; float lo, hi, a, b; };
 
 template <bool FAST, bool NEED_DIST>
 PT_DEV Hit closest_intersection(cfloat_p geom, int n_surfaces, V3 o, V3 d,
                                 unsigned long long *redo_count = nullptr)
 {
     using N = Num<FAST>;
-    Best best = {-1, 0, 0.0f, 0.0f, 0.0f, 0.0f};
+    const float INF = __builtin_inff();
+    Best best = {-4, INF, INF, 0.0f, 0.0f};
     bool unsure = false;
     const V3 nd = -d;
     const float len_d = __builtin_amdgcn_sqrtf(N::dot(d, d));
@@ -381,28 +383,30 @@ PT_DEV Hit closest_intersection(cfloat_p geom, int n_surfaces, V3 o, V3 d,
         bool acc;           // surely a hit (FAST: a hit)
         bool rej;           // surely not a hit
         int mode;
-        float dist, err, a, b;
+        float c_lo, c_hi, a, b;
         if (__builtin_bit_cast(int, g[3]) == 0) {    // wave-uniform branch
             const TriDets q = triangle_dets<FAST>(g, o, nd);
             const float inv = __builtin_amdgcn_rcpf(q.det_a);
             const float u = q.du * inv, v = q.dv * inv, t = q.dt * inv;
             const float s = u + v;
             const bool det_bad = q.det_a >= -EPS_F && q.det_a <= EPS_F;
+            const float dist = t * len_d;
+            // non-short-circuit on purpose: every comparison is one instruction
             if constexpr (FAST) {
                 acc = !(det_bad | (u < -EPS_F) | (u >= 1.0f) | (v < -EPS_F) | (s >= 1.0f) | (t <= EPS_F));
                 rej = !acc;
+                c_lo = c_hi = dist;
             } else {
-                // non-short-circuit on purpose: every comparison is one instruction
                 rej = det_bad | (u < BAND_LO_REJ) | (u > BAND_ONE_REJ) | (v < BAND_LO_REJ) |
                       (s > BAND_ONE_REJ) | (t < BAND_T_REJ);
                 acc = !det_bad & (u > BAND_LO_ACC) & (u < BAND_ONE_ACC) & (v > BAND_LO_ACC) &
                       (s < BAND_ONE_ACC) & (t > BAND_T_ACC);
+                c_lo = dist * (1.0f - TRI_DIST_ERR);
+                c_hi = dist * (1.0f + TRI_DIST_ERR);
             }
             mode = 0;
             a = q.dt;
             b = q.det_a;
-            dist = t * len_d;
-            err = dist * TRI_DIST_ERR;
         } else {
             float tca, arg;
             const bool pre_ok = sphere_pre<FAST>(g, o, d, tca, arg);
@@ -410,43 +414,45 @@ PT_DEV Hit closest_intersection(cfloat_p geom, int n_surfaces, V3 o, V3 d,
             const float t1 = tca - thc, t2 = tca + thc;
             if constexpr (FAST) {
                 const bool near = !(t1 <= EPS_F);
-                dist = near ? t1 : t2;
-                acc = pre_ok & !(dist <= EPS_F);
+                c_lo = c_hi = near ? t1 : t2;
+                acc = pre_ok & !(c_lo <= EPS_F);
                 rej = !acc;
                 mode = near ? 1 : 2;
-                err = 0.0f;
             } else {
                 const float e1 = SPH_DIST_ERR * (thc + __builtin_fabsf(t1));
                 const float e2 = SPH_DIST_ERR * (thc + __builtin_fabsf(t2));
-                const bool near_ok = t1 - e1 > BAND_T_ACC, near_bad = t1 + e1 < BAND_T_REJ;
-                const bool far_ok = t2 - e2 > BAND_T_ACC, far_bad = t2 + e2 < BAND_T_REJ;
+                const float lo1 = t1 - e1, hi1 = t1 + e1, lo2 = t2 - e2, hi2 = t2 + e2;
+                const bool near_ok = lo1 > BAND_T_ACC, near_bad = hi1 < BAND_T_REJ;
+                const bool far_ok = lo2 > BAND_T_ACC, far_bad = hi2 < BAND_T_REJ;
                 acc = pre_ok & (near_ok | (near_bad & far_ok));
                 rej = !pre_ok | (near_bad & far_bad);
-                dist = near_ok ? t1 : t2;
-                err = near_ok ? e1 : e2;
+                c_lo = near_ok ? lo1 : lo2;
+                c_hi = near_ok ? hi1 : hi2;
                 mode = near_ok ? 1 : 2;
             }
             a = tca;
             b = arg;
         }
-        if constexpr (FAST) {
-            if (acc & ((best.idx < 0) | (dist < best.dist))) best = {i, mode, dist, 0.0f, a, b};
-        } else {
-            // src/main.cpp:61: replace only when strictly closer
-            const bool closer = (best.idx < 0) | (dist + err < best.dist - best.err);
-            const bool not_closer = dist - err > best.dist + best.err;
-            unsure = unsure | !(acc | rej) | (acc & !(closer | not_closer));
-            if (acc & closer) best = {i, mode, dist, err, a, b};
+        // a candidate that is not a hit never wins and never ties
+        c_lo = acc ? c_lo : INF;
+        c_hi = acc ? c_hi : INF;
+        // src/main.cpp:61: a later surface replaces the current one only when strictly closer
+        const bool closer = c_hi < best.lo;
+        if constexpr (!FAST) {
+            const bool not_closer = c_lo >= best.hi;
+            unsure = unsure | !(acc | rej) | !(closer | not_closer);
         }
+        if (closer) best = {4 * i + mode, c_lo, c_hi, a, b};
     }
 
     Hit h;
-    h.idx = best.idx;
+    h.idx = best.code >> 2;
     h.t = 0.0f;
     h.dist = 0.0f;
+    const int mode = best.code & 3;
     if constexpr (FAST) {
-        h.t = best.mode == 0 ? best.a * __builtin_amdgcn_rcpf(best.b) : best.dist;
-        h.dist = best.dist;
+        h.t = mode == 0 ? best.a * __builtin_amdgcn_rcpf(best.b) : best.lo;
+        h.dist = best.lo;
         return h;
     } else {
         if (__any(unsure)) {                         // rare: redo those lanes directly
@@ -455,8 +461,8 @@ PT_DEV Hit closest_intersection(cfloat_p geom, int n_surfaces, V3 o, V3 d,
                 return closest_direct<false>(geom, n_surfaces, o, d);
             }
         }
-        if (best.idx >= 0) {
-            if (best.mode == 0) {
+        if (h.idx >= 0) {
+            if (mode == 0) {
                 h.t = best.a / best.b;                              // surface.hpp:65
                 if constexpr (NEED_DIST) {
                     const V3 td = d * h.t;                          // surface.hpp:70
@@ -464,7 +470,7 @@ PT_DEV Hit closest_intersection(cfloat_p geom, int n_surfaces, V3 o, V3 d,
                 }
             } else {
                 const float thc = __builtin_sqrtf(best.b);          // surface.hpp:101
-                h.t = best.mode == 1 ? best.a - thc : best.a + thc;
+                h.t = mode == 1 ? best.a - thc : best.a + thc;
                 h.dist = h.t;                                       // surface.hpp:111
             }
         }
