@@ -76,6 +76,7 @@ def main():
     import torch
     import torch.distributed as dist
     import pt_amd
+    import pt_dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -98,11 +99,10 @@ def main():
     accum = torch.zeros(height, width, 3, dtype=torch.float32, device="cuda")
 
     def step(i):
-        # global sample numbers: step-major, then rank, so no two (step, rank) overlap
-        first = (i * world + rank) * args.spp
-        ctx.render_into(accum.data_ptr(), args.spp, first, args.seed, mode)
-        if world > 1:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)   # rank 0 now holds the sum of all images
+        # step i renders global samples [i*world*spp, (i+1)*world*spp), split over the ranks
+        pt_dist.render_share(ctx, accum, args.spp * world, world, rank,
+                             first_sample=i * world * args.spp, seed=args.seed, mode=mode)
+        pt_dist.reduce_image(accum, dst=0)       # one RCCL reduce; a no-op on one GPU
 
     def fence():
         if world > 1:

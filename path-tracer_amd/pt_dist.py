@@ -1,0 +1,42 @@
+"""Multi-GPU render step: one process per GPU, samples-per-pixel partitioned by
+global sample number, images combined with ONE reduce (RCCL over xGMI when the
+process group's backend is "nccl").
+
+The random stream of a path depends only on (seed, pixel, global sample
+number), so the union of the ranks' samples is the same set of paths whatever
+the number of GPUs: an N-GPU image differs from the 1-GPU image only by the
+order of fp32 additions.  The reference has no counterpart (it is a single
+thread); its running sum `buffer[u][v] += color` (src/main.cpp:139) is what
+makes the partition exact.
+"""
+
+
+def partition_samples(total_spp, world, rank, first_sample=0):
+    """Contiguous share of global samples [first_sample, first_sample+total_spp)
+    for `rank` of `world`: returns (first, count).  Shares differ by at most one
+    sample and tile the range exactly; a share may be empty when world > total_spp."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError("rank %d of world %d" % (rank, world))
+    if total_spp < 0:
+        raise ValueError("total_spp must be non-negative")
+    lo = rank * total_spp // world
+    hi = (rank + 1) * total_spp // world
+    return first_sample + lo, hi - lo
+
+
+def render_share(renderer, accum, total_spp, world, rank, first_sample=0, seed=1, mode=0):
+    """Adds this rank's share of the samples into `accum` (a torch tensor of
+    height x width x 3 float32 on the renderer's device).  `renderer` offers
+    render_into(device_ptr, spp, first_sample, seed, mode), as pt_amd.Context does."""
+    first, count = partition_samples(total_spp, world, rank, first_sample)
+    if count > 0:
+        renderer.render_into(accum.data_ptr(), count, first, seed, mode)
+    return count
+
+
+def reduce_image(accum, dst=0, group=None):
+    """Sums the ranks' accumulation buffers onto rank `dst` with one collective."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    return accum
