@@ -28,7 +28,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd"))
 
-FP32_VECTOR_PEAK_TFLOPS = 157.3      # MI355X: 256 CU x 128 lanes x 2 (packed) x 2 (fma) x 2.4 GHz
+FP32_VECTOR_PEAK_TFLOPS = 157.3      # MI355X: 256 CU x 4 SIMD x 32 lanes x 2 flop (fma) x 2.4 GHz
 
 
 def parse():
@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--size", type=int, nargs=2, default=[800, 800], metavar=("W", "H"))
     ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per step per GPU")
     ap.add_argument("--numeric", choices=["exact", "fast"], default="exact")
+    ap.add_argument("--layout", choices=["megakernel", "wavefront"], default="megakernel")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-spp", type=int, default=12,
                     help="samples per pixel of the CPU baseline's bounded sample (0 = skip)")
@@ -91,7 +92,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     width, height = args.size
-    mode = pt_amd.MODE_MEGAKERNEL | (pt_amd.NUM_FAST if args.numeric == "fast" else pt_amd.NUM_EXACT)
+    mode = (pt_amd.MODE_WAVEFRONT if args.layout == "wavefront" else pt_amd.MODE_MEGAKERNEL) | \
+           (pt_amd.NUM_FAST if args.numeric == "fast" else pt_amd.NUM_EXACT)
     scene = pt_amd.builtin_scene(args.scene, width, height)
     ctx = pt_amd.Context(local_rank)
     ctx.load(scene)
@@ -148,16 +150,17 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "%s %dx%d, %d spp per GPU per step, megakernel, %s arithmetic" % (
-                           args.scene, width, height, args.spp, args.numeric),
+            "config": {"workload": "%s %dx%d, %d spp per GPU per step, %s, %s arithmetic" % (
+                           args.scene, width, height, args.spp, args.layout, args.numeric),
                        "scene": args.scene, "width": width, "height": height, "spp_per_gpu": args.spp,
-                       "layout": "megakernel", "numeric": args.numeric,
+                       "layout": args.layout, "numeric": args.numeric,
                        "parallelism": "spp-partition x%d + one RCCL reduce per step" % world
                                       if world > 1 else "single GPU"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP32_VECTOR_PEAK_TFLOPS,
                          "traffic": pmc_traffic(),
-                         "kernel": "k_render_mega", "kernel_ms": avg_ms,
+                         "kernel": "k_render_mega" if args.layout == "megakernel" else "k_wf_bounce (all launches)",
+                         "kernel_ms": avg_ms,
                          "flops_per_launch": sum(flops) / len(flops)},
             "tests_per_s": sum(segments) / len(segments) * n_surf / (avg_ms * 1e-3),
             "segments_per_sample": sum(segments) / len(segments) / (width * height * args.spp),

@@ -85,7 +85,7 @@ typedef struct pt_counters {
     double total_ms;           /* the same including the partial-sum reduction */
     double flops;              /* algorithmic flops: segments x (63 n_tri + 18 n_sph) */
     uint32_t vgprs;            /* registers per lane of the render kernel */
-    uint32_t grid_blocks;      /* workgroups launched */
+    uint32_t grid_blocks;      /* megakernel: workgroups launched; wavefront: bounce launches */
 } pt_counters;
 
 typedef struct pt_ctx pt_ctx;

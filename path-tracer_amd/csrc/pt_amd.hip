@@ -66,6 +66,11 @@ struct pt_ctx {
     uint32_t *d_queue = nullptr;     // [0] work counter; [2..3], [4..5]: 64-bit segment and redo counters
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 
+    // wavefront layout: two sets of path-state arrays, per-path results, live counts
+    void *d_wf = nullptr;
+    size_t wf_paths = 0;
+    uint32_t *d_wf_counts = nullptr; // [0], [1]: live paths in set 0 / set 1
+
     int num_cus = 0;
     pt_counters last{};
     bool last_valid = false, last_pending = false;
@@ -207,13 +212,121 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
     return PT_OK;
 }
 
+// Queue-per-bounce layout.  Samples are rendered in batches of whole samples per
+// pixel, as many as fit the path-state budget; per batch: one generate launch,
+// one bounce launch per path depth until no path is alive (the live count is
+// read back after every bounce to size the next launch), one reduce launch.
+constexpr size_t WF_MAX_PATHS = 48u << 20;          // 48 Mi paths: 2 x 3 GiB of state + 576 MiB of results
+constexpr size_t WF_BYTES_PER_PATH = 2 * 64 + 12;
+
+template <bool FAST>
+int launch_wavefront(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample, uint64_t seed)
+{
+    const uint32_t n_pixels = (uint32_t)ctx->cam.width * (uint32_t)ctx->cam.height;
+    if (n_pixels > WF_MAX_PATHS)
+        return fail(ctx, PT_E_LIMIT, "image of %u pixels exceeds the wavefront layout's %zu paths", n_pixels, WF_MAX_PATHS);
+    const uint32_t batch_spp_max = (uint32_t)std::min<size_t>(spp, WF_MAX_PATHS / n_pixels);
+    const size_t max_paths = (size_t)batch_spp_max * n_pixels;
+    if (max_paths > ctx->wf_paths) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_wf) (void)hipFree(ctx->d_wf);
+        ctx->d_wf = nullptr;
+        ctx->wf_paths = 0;
+        hipError_t e = hipMalloc(&ctx->d_wf, max_paths * WF_BYTES_PER_PATH);
+        if (e != hipSuccess) return fail(ctx, PT_E_NOMEM, "hipMalloc of %zu bytes of path state failed: %s",
+                                         max_paths * WF_BYTES_PER_PATH, hipGetErrorString(e));
+        ctx->wf_paths = max_paths;
+    }
+    if (!ctx->d_wf_counts) {
+        int rc = dev_alloc(ctx, &ctx->d_wf_counts, 2);
+        if (rc) return rc;
+    }
+    // carve: set 0 {a,b,c,d}, set 1 {a,b,c,d}, results
+    char *base = static_cast<char *>(ctx->d_wf);
+    const size_t q = ctx->wf_paths * 16;
+    WfArrays sets[2];
+    for (int k = 0; k < 2; k++) {
+        sets[k].a = reinterpret_cast<float4 *>(base + (4 * k + 0) * q);
+        sets[k].b = reinterpret_cast<float4 *>(base + (4 * k + 1) * q);
+        sets[k].c = reinterpret_cast<float4 *>(base + (4 * k + 2) * q);
+        sets[k].d = reinterpret_cast<uint4 *>(base + (4 * k + 3) * q);
+    }
+    float *result = reinterpret_cast<float *>(base + 8 * q);
+
+    WfParams P{};
+    P.cam = ctx->cam;
+    P.geom = ctx->d_geom;
+    P.shade = ctx->d_shade;
+    P.n_surfaces = ctx->n_surfaces;
+    memcpy(P.bg, ctx->bg, sizeof P.bg);
+    P.seed_mix = host_seed_mix(seed);
+    P.n_pixels = n_pixels;
+    P.result = result;
+    P.stats = reinterpret_cast<unsigned long long *>(ctx->d_queue + 2);
+    const size_t lds_bytes = (size_t)ctx->n_surfaces * SHADE_STRIDE * sizeof(float);
+
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 32, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    uint64_t segments = 0;
+    uint32_t launches = 0;
+    for (uint32_t done = 0; done < spp;) {
+        const uint32_t batch_spp = std::min(batch_spp_max, spp - done);
+        const uint32_t n_paths = batch_spp * n_pixels;
+        P.first_sample = first_sample + done;
+        P.n_paths = n_paths;
+        P.in = sets[0];
+        hipLaunchKernelGGL(k_wf_generate, dim3(blocks_for(n_paths)), dim3(BLOCK), 0, ctx->stream, P);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_wf_counts, &n_paths, 4, hipMemcpyHostToDevice, ctx->stream));
+        uint32_t live = n_paths;
+        int cur = 0;
+        while (live > 0) {
+            P.in = sets[cur];
+            P.out = sets[cur ^ 1];
+            P.n_in = ctx->d_wf_counts + cur;
+            P.n_out = ctx->d_wf_counts + (cur ^ 1);
+            HIP_TRY(ctx, hipMemsetAsync(P.n_out, 0, 4, ctx->stream));
+            hipLaunchKernelGGL(k_wf_bounce<FAST>, dim3(blocks_for(live)), dim3(BLOCK), lds_bytes, ctx->stream, P);
+            HIP_TRY(ctx, hipGetLastError());
+            segments += live;
+            launches++;
+            HIP_TRY(ctx, hipMemcpyAsync(&live, P.n_out, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            cur ^= 1;
+        }
+        const size_t n = (size_t)n_pixels * 3;
+        hipLaunchKernelGGL(k_wf_reduce, dim3(blocks_for((long long)n)), dim3(BLOCK), 0, ctx->stream,
+                           result, batch_spp, n, accum);
+        HIP_TRY(ctx, hipGetLastError());
+        done += batch_spp;
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    // the bounce launches know their own segment counts: put the total where pt_get_counters reads it
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_queue + 2, &segments, 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+    hipFuncAttributes attr{};
+    HIP_TRY(ctx, hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k_wf_bounce<FAST>)));
+    ctx->last = pt_counters{};
+    ctx->last.samples = (uint64_t)n_pixels * spp;
+    ctx->last.vgprs = (uint32_t)attr.numRegs;
+    ctx->last.grid_blocks = launches;
+    ctx->last_valid = true;
+    ctx->last_pending = true;
+    return PT_OK;
+}
+
 int render_dispatch(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample, uint64_t seed, int mode)
 {
     if (spp == 0) return fail(ctx, PT_E_INVALID, "spp must be positive");
     if ((uint64_t)first_sample + spp > 0xFFFFFFFFull)
         return fail(ctx, PT_E_LIMIT, "sample numbers must fit in 32 bits");
     if (mode & ~(PT_MODE_WAVEFRONT | PT_NUM_FAST)) return fail(ctx, PT_E_INVALID, "unknown mode bits 0x%x", mode);
-    if (mode & PT_MODE_WAVEFRONT) return fail(ctx, PT_E_INVALID, "the wavefront layout is not built");
+    if (mode & PT_MODE_WAVEFRONT) {
+        if (mode & PT_NUM_FAST) return launch_wavefront<true>(ctx, accum, spp, first_sample, seed);
+        return launch_wavefront<false>(ctx, accum, spp, first_sample, seed);
+    }
     if (mode & PT_NUM_FAST) return launch_render<true>(ctx, accum, spp, first_sample, seed);
     return launch_render<false>(ctx, accum, spp, first_sample, seed);
 }
@@ -265,6 +378,8 @@ void pt_destroy(pt_ctx *ctx)
     if (ctx->d_accum) (void)hipFree(ctx->d_accum);
     if (ctx->d_slabs) (void)hipFree(ctx->d_slabs);
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
+    if (ctx->d_wf) (void)hipFree(ctx->d_wf);
+    if (ctx->d_wf_counts) (void)hipFree(ctx->d_wf_counts);
     delete ctx;
 }
 

@@ -113,6 +113,86 @@ k_rng_uniform(uint32_t seed_mix, const uint32_t *pixel, const uint32_t *sample,
     out[i] = rng_at(r, draw[i]);
 }
 
+// ---------------------------------------------------------------- one path segment
+
+// A path between two segments: what both kernel layouts carry per path.
+struct PathState {
+    V3 o, d;            // ray of the next segment
+    V3 thr, col;        // throughput and radiance so far
+    Rng rng;
+    int depth;
+};
+
+// The start of a path: trace_rays' per-pixel set-up, src/main.cpp:120-136.
+PT_DEV void path_begin(PathState &ps, const Camera &cam, uint32_t pixel_key, uint32_t sample, int px, int py)
+{
+    ps.rng = rng_path(pixel_key, sample);
+    const float xu = rng_next(ps.rng), xv = rng_next(ps.rng);
+    float xr = 0.0f, xp = 0.0f;
+    if (cam.dof_on) { xr = rng_next(ps.rng); xp = rng_next(ps.rng); }
+    camera_ray<true>(cam, px, py, xu, xv, xr, xp, ps.o, ps.d);
+    ps.col = v3(0, 0, 0);
+    ps.thr = v3(1, 1, 1);
+    ps.depth = 0;
+}
+
+// One iteration of trace_ray's loop, src/main.cpp:84-109.  Returns true when the
+// path has ended (ps.col is then its radiance).  shade = the scene's shading
+// records (LDS).
+//
+// FAST selects the arithmetic of the closest-hit search and of the hit point:
+// EXACT finds, for every ray, the surface and parameter t the reference's
+// arithmetic finds.  Quantities that are continuous functions of random
+// numbers - the jittered camera ray, sphere normals, sampled directions,
+// throughput - use fused multiply-adds and the hardware reciprocal/root/sine
+// (each within 1 ulp) in both modes: the reference evaluates them through libm
+// in double, which no fp32 path matches bit for bit, and they are checked to
+// 1e-5 instead.
+template <bool FAST>
+PT_DEV bool path_segment(PathState &ps, cfloat_p geom, int n_surfaces, const float *shade,
+                         const float (&bg)[3], unsigned long long *redo_count)
+{
+    using N = Num<FAST>;
+    using S = Num<true>;
+    const Hit h = closest_intersection<FAST, false>(geom, n_surfaces, ps.o, ps.d, redo_count);
+    if (h.idx < 0) {                                // main.cpp:105-108
+        ps.col = v3(S::mad(bg[0], ps.thr.x, ps.col.x), S::mad(bg[1], ps.thr.y, ps.col.y),
+                    S::mad(bg[2], ps.thr.z, ps.col.z));
+        return true;
+    }
+    const float4 r0 = *reinterpret_cast<const float4 *>(shade + h.idx * SHADE_STRIDE);
+    const float4 r1 = *reinterpret_cast<const float4 *>(shade + h.idx * SHADE_STRIDE + 4);
+    const float4 r2 = *reinterpret_cast<const float4 *>(shade + h.idx * SHADE_STRIDE + 8);
+    const int flags = __builtin_bit_cast(int, r0.w);
+    const int type = flags & 0xff;
+    const V3 point = N::along(ps.o, ps.d, h.t);
+    V3 normal = v3(r2.x, r2.y, r2.z);
+    if (flags >> 8) normal = S::normalize(point - normal);       // sphere, surface.hpp:86-88
+    float xi0 = 0.0f, xi1 = 0.0f;
+    if (type == 0) { xi0 = rng_next(ps.rng); xi1 = rng_next(ps.rng); }
+    else if (type == 2) { xi0 = rng_next(ps.rng); }
+    const V3 new_dir = sample_pdf<true>(type, normal, ps.d, xi0, xi1);
+    ps.o = point;
+    ps.col = v3(S::mad(r1.x, ps.thr.x, ps.col.x), S::mad(r1.y, ps.thr.y, ps.col.y),
+                S::mad(r1.z, ps.thr.z, ps.col.z));             // emission at every hit, main.cpp:92
+    ps.thr = ps.thr * brdf<true>(type, v3(r0.x, r0.y, r0.z), normal, new_dir);
+    ps.d = new_dir;
+    bool ended = false;
+    if (ps.depth >= 5) {                            // russian roulette, main.cpp:97-104
+        if (ps.depth + 1 >= MAX_DEPTH) {
+            ended = true;
+        } else {
+            float m = ps.thr.y < ps.thr.z ? ps.thr.z : ps.thr.y;
+            m = ps.thr.x < m ? m : ps.thr.x;
+            const float p = m < 0.0f ? 0.0f : (0.95f < m ? 0.95f : m);
+            if (rng_next(ps.rng) > p) ended = true;
+            else ps.thr = ps.thr * S::div(1.0f, p);
+        }
+    }
+    ps.depth++;
+    return ended;
+}
+
 // ---------------------------------------------------------------- megakernel
 
 // Persistent lanes.  A lane owns one work item (pixel, chunk of samples) at a
@@ -126,16 +206,6 @@ template <bool FAST>
 __global__ void __launch_bounds__(BLOCK)
 k_render_mega(RenderParams P)
 {
-    // FAST selects the arithmetic of the closest-hit search (and of the hit
-    // point): EXACT finds, for every ray, the surface and parameter t the
-    // reference's arithmetic finds.  Quantities that are continuous functions
-    // of random numbers - the jittered camera ray, sphere normals, sampled
-    // directions, throughput - use fused multiply-adds and the hardware
-    // reciprocal/root/sine (each within 1 ulp) in both modes: the reference
-    // evaluates them through libm in double, which no fp32 path matches bit
-    // for bit, and they are checked to 1e-5 instead.
-    using N = Num<FAST>;
-    using S = Num<true>;
     extern __shared__ __align__(16) float lds_shade[];
     for (int i = threadIdx.x; i < P.n_surfaces * SHADE_STRIDE; i += BLOCK)
         lds_shade[i] = P.shade[i];
@@ -151,10 +221,9 @@ k_render_mega(RenderParams P)
 
     bool have_item = false, need_path = true;
     uint32_t item = 0, pixel = 0, pixel_key = 0, s = 0, s_end = 0;
-    int px = 0, py = 0, depth = 0;
-    V3 sum = v3(0, 0, 0), col = v3(0, 0, 0), thr = v3(1, 1, 1);
-    V3 o = v3(0, 0, 0), d = v3(0, 0, 1);
-    Rng rng = {0, 0};
+    int px = 0, py = 0;
+    V3 sum = v3(0, 0, 0);
+    PathState ps = {v3(0, 0, 0), v3(0, 0, 1), v3(1, 1, 1), v3(0, 0, 0), {0, 0}, 0};
     unsigned long long n_seg = 0;
 
     for (;;) {
@@ -204,59 +273,14 @@ k_render_mega(RenderParams P)
                 pixel_key = rng_pixel(P.seed_mix, pixel);
             }
         }
-        if (need_path) {                        // trace_rays' per-pixel set-up, main.cpp:120-136
-            rng = rng_path(pixel_key, s);
-            const float xu = rng_next(rng), xv = rng_next(rng);
-            float xr = 0.0f, xp = 0.0f;
-            if (P.cam.dof_on) { xr = rng_next(rng); xp = rng_next(rng); }
-            camera_ray<true>(P.cam, px, py, xu, xv, xr, xp, o, d);
-            col = v3(0, 0, 0);
-            thr = v3(1, 1, 1);
-            depth = 0;
+        if (need_path) {
+            path_begin(ps, P.cam, pixel_key, s, px, py);
             need_path = false;
         }
-
-        // one iteration of trace_ray's loop, main.cpp:84-109
-        const Hit h = closest_intersection<FAST, false>(geom, P.n_surfaces, o, d, P.stats + 1);
+        const bool ended = path_segment<FAST>(ps, geom, P.n_surfaces, lds_shade, P.bg, P.stats + 1);
         n_seg++;
-        bool ended;
-        if (h.idx < 0) {
-            col = v3(S::mad(P.bg[0], thr.x, col.x), S::mad(P.bg[1], thr.y, col.y),
-                     S::mad(P.bg[2], thr.z, col.z));
-            ended = true;
-        } else {
-            const float4 r0 = *reinterpret_cast<const float4 *>(lds_shade + h.idx * SHADE_STRIDE);
-            const float4 r1 = *reinterpret_cast<const float4 *>(lds_shade + h.idx * SHADE_STRIDE + 4);
-            const float4 r2 = *reinterpret_cast<const float4 *>(lds_shade + h.idx * SHADE_STRIDE + 8);
-            const int flags = __builtin_bit_cast(int, r0.w);
-            const int type = flags & 0xff;
-            const V3 point = N::along(o, d, h.t);
-            V3 normal = v3(r2.x, r2.y, r2.z);
-            if (flags >> 8) normal = S::normalize(point - normal);   // sphere, surface.hpp:86-88
-            float xi0 = 0.0f, xi1 = 0.0f;
-            if (type == 0) { xi0 = rng_next(rng); xi1 = rng_next(rng); }
-            else if (type == 2) { xi0 = rng_next(rng); }
-            const V3 new_dir = sample_pdf<true>(type, normal, d, xi0, xi1);
-            o = point;
-            col = v3(S::mad(r1.x, thr.x, col.x), S::mad(r1.y, thr.y, col.y), S::mad(r1.z, thr.z, col.z));
-            thr = thr * brdf<true>(type, v3(r0.x, r0.y, r0.z), normal, new_dir);
-            d = new_dir;
-            ended = false;
-            if (depth >= 5) {                   // russian roulette, main.cpp:97-104
-                if (depth + 1 >= MAX_DEPTH) {
-                    ended = true;
-                } else {
-                    float m = thr.y < thr.z ? thr.z : thr.y;
-                    m = thr.x < m ? m : thr.x;
-                    const float p = m < 0.0f ? 0.0f : (0.95f < m ? 0.95f : m);
-                    if (rng_next(rng) > p) ended = true;
-                    else thr = thr * S::div(1.0f, p);
-                }
-            }
-            depth++;
-        }
         if (ended) {
-            sum = sum + col;                    // buffer[u][v] += color, main.cpp:139
+            sum = sum + ps.col;                 // buffer[u][v] += color, main.cpp:139
             s++;
             need_path = true;
         }
@@ -272,6 +296,106 @@ k_reduce_slabs(const float *slabs, uint32_t n_chunks, size_t n, float *accum)
     if (i >= n) return;
     float a = accum[i];
     for (uint32_t k = 0; k < n_chunks; k++) a += slabs[(size_t)k * n + i];
+    accum[i] = a;
+}
+
+// ---------------------------------------------------------------- wavefront layout
+
+// Queue-per-bounce layout: the state of every live path sits in HBM, 64 bytes
+// per path as four 16-byte quarters (each read or written by one coalesced
+// 1 KiB wave instruction); one kernel advances every live path by one segment
+// and writes the survivors, compacted, to the other set of arrays.
+//   a = (o.x, o.y, o.z, d.x)   b = (d.y, d.z, thr.x, thr.y)
+//   c = (thr.z, col.x, col.y, col.z)   d = (rng key, rng counter, depth, slot)
+// slot = sample_in_batch * n_pixels + pixel: where the path's radiance goes.
+struct WfArrays { float4 *a, *b, *c; uint4 *d; };
+
+struct WfParams {
+    Camera cam;
+    const float *geom, *shade;
+    int n_surfaces;
+    float bg[3];
+    uint32_t seed_mix;
+    uint32_t first_sample;     // global number of the batch's first sample
+    uint32_t n_pixels;
+    uint32_t n_paths;          // generate: paths in the batch
+    WfArrays in, out;
+    const uint32_t *n_in;      // bounce: number of live paths in `in`
+    uint32_t *n_out;           // bounce: survivors appended to `out` (zeroed before the launch)
+    float *result;             // radiance of finished paths, 3 floats per slot
+    unsigned long long *stats; // [1] += segments re-evaluated directly
+};
+
+PT_DEV void wf_store(const WfArrays &w, uint32_t i, const PathState &ps, uint32_t slot)
+{
+    w.a[i] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
+    w.b[i] = make_float4(ps.d.y, ps.d.z, ps.thr.x, ps.thr.y);
+    w.c[i] = make_float4(ps.thr.z, ps.col.x, ps.col.y, ps.col.z);
+    w.d[i] = make_uint4(ps.rng.key, ps.rng.ctr, (uint32_t)ps.depth, slot);
+}
+
+__global__ void __launch_bounds__(BLOCK)
+k_wf_generate(WfParams P)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= P.n_paths) return;
+    const uint32_t s = i / P.n_pixels, pixel = i - s * P.n_pixels;
+    PathState ps;
+    path_begin(ps, P.cam, rng_pixel(P.seed_mix, pixel), P.first_sample + s,
+               (int)(pixel % (uint32_t)P.cam.width), (int)(pixel / (uint32_t)P.cam.width));
+    wf_store(P.in, i, ps, i);
+}
+
+template <bool FAST>
+__global__ void __launch_bounds__(BLOCK)
+k_wf_bounce(WfParams P)
+{
+    extern __shared__ __align__(16) float lds_shade[];
+    for (int i = threadIdx.x; i < P.n_surfaces * SHADE_STRIDE; i += BLOCK)
+        lds_shade[i] = P.shade[i];
+    __syncthreads();
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    const bool live = i < *P.n_in;
+    bool survives = false;
+    PathState ps;
+    uint32_t slot = 0;
+    if (live) {
+        const float4 a = P.in.a[i], b = P.in.b[i], c = P.in.c[i];
+        const uint4 d = P.in.d[i];
+        ps.o = v3(a.x, a.y, a.z);
+        ps.d = v3(a.w, b.x, b.y);
+        ps.thr = v3(b.z, b.w, c.x);
+        ps.col = v3(c.y, c.z, c.w);
+        ps.rng.key = d.x;
+        ps.rng.ctr = d.y;
+        ps.depth = (int)d.z;
+        slot = d.w;
+        const bool ended = path_segment<FAST>(ps, as_constant(P.geom), P.n_surfaces, lds_shade, P.bg, P.stats + 1);
+        if (ended) {
+            float *r = P.result + 3ull * slot;
+            r[0] = ps.col.x; r[1] = ps.col.y; r[2] = ps.col.z;
+        }
+        survives = !ended;
+    }
+    // compaction: one counter add per wave, survivors packed in lane order
+    const unsigned long long mask = __ballot(survives);
+    if (mask) {
+        const uint32_t lane = __lane_id();
+        uint32_t base = 0;
+        if (lane == (uint32_t)__ffsll((long long)mask) - 1u) base = atomicAdd(P.n_out, (uint32_t)__popcll(mask));
+        base = (uint32_t)__shfl((int)base, __ffsll((long long)mask) - 1);
+        if (survives) wf_store(P.out, base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), ps, slot);
+    }
+}
+
+// accum[p] += result of sample 0, 1, ... of the batch, in sample order (n = n_pixels * 3)
+__global__ void __launch_bounds__(BLOCK)
+k_wf_reduce(const float *result, uint32_t batch_spp, size_t n, float *accum)
+{
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float a = accum[i];
+    for (uint32_t s = 0; s < batch_spp; s++) a += result[(size_t)s * n + i];
     accum[i] = a;
 }
 

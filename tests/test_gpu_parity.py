@@ -350,3 +350,19 @@ def test_error_paths(pt):
         c.close()
     with pytest.raises(pt.PtError):
         pt.Context(4096)
+
+
+# ---------------------------------------------------------------- wavefront layout
+
+@pytest.mark.parametrize("name", ["cornell_2", "orange_plane"])
+def test_wavefront_equals_megakernel(ctx, pt, name):
+    """Same paths in both layouts (same generator, same arithmetic): equal segment counts,
+    images equal up to the order of the fp32 additions."""
+    sc = pt.builtin_scene(name, 120, 80)
+    mega, cm = render(ctx, pt, sc, 20, first=7, seed=3, mode=pt.MODE_MEGAKERNEL)
+    wave, cw = render(ctx, pt, sc, 20, first=7, seed=3, mode=pt.MODE_WAVEFRONT)
+    assert cw.segments == cm.segments and cw.samples == cm.samples
+    assert np.allclose(wave, mega, rtol=1e-5, atol=1e-6)
+    fast, cf = render(ctx, pt, sc, 20, first=7, seed=3, mode=pt.MODE_WAVEFRONT | pt.NUM_FAST)
+    assert abs(int(cf.segments) - int(cm.segments)) < 0.01 * cm.segments
+    assert np.allclose(fast.mean((0, 1)), mega.mean((0, 1)), rtol=0.02)
