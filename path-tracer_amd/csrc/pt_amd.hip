@@ -214,10 +214,11 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
 
 // Queue-per-bounce layout.  Samples are rendered in batches of whole samples per
 // pixel, as many as fit the path-state budget; per batch: one generate launch,
-// one bounce launch per path depth until no path is alive (the live count is
+// one bounce launch per path depth until no path is alive (the live counts are
 // read back after every bounce to size the next launch), one reduce launch.
 constexpr size_t WF_MAX_PATHS = 48u << 20;          // 48 Mi paths: 2 x 3 GiB of state + 576 MiB of results
 constexpr size_t WF_BYTES_PER_PATH = 2 * 64 + 12;
+constexpr size_t WF_COUNT_WORDS = (size_t)WF_SHARDS * WF_COUNT_STRIDE;
 
 template <bool FAST>
 int launch_wavefront(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample, uint64_t seed)
@@ -227,18 +228,24 @@ int launch_wavefront(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sam
         return fail(ctx, PT_E_LIMIT, "image of %u pixels exceeds the wavefront layout's %zu paths", n_pixels, WF_MAX_PATHS);
     const uint32_t batch_spp_max = (uint32_t)std::min<size_t>(spp, WF_MAX_PATHS / n_pixels);
     const size_t max_paths = (size_t)batch_spp_max * n_pixels;
-    if (max_paths > ctx->wf_paths) {
+    // a region holds the workgroups g with g % WF_SHARDS == shard, whole workgroups
+    auto shard_cap_for = [](size_t paths) {
+        const size_t groups = (paths + BLOCK - 1) / BLOCK;
+        return (uint32_t)(((groups + WF_SHARDS - 1) / WF_SHARDS) * BLOCK);
+    };
+    const size_t alloc_paths = (size_t)shard_cap_for(max_paths) * WF_SHARDS;
+    if (alloc_paths > ctx->wf_paths) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->d_wf) (void)hipFree(ctx->d_wf);
         ctx->d_wf = nullptr;
         ctx->wf_paths = 0;
-        hipError_t e = hipMalloc(&ctx->d_wf, max_paths * WF_BYTES_PER_PATH);
+        hipError_t e = hipMalloc(&ctx->d_wf, alloc_paths * WF_BYTES_PER_PATH);
         if (e != hipSuccess) return fail(ctx, PT_E_NOMEM, "hipMalloc of %zu bytes of path state failed: %s",
-                                         max_paths * WF_BYTES_PER_PATH, hipGetErrorString(e));
-        ctx->wf_paths = max_paths;
+                                         alloc_paths * WF_BYTES_PER_PATH, hipGetErrorString(e));
+        ctx->wf_paths = alloc_paths;
     }
     if (!ctx->d_wf_counts) {
-        int rc = dev_alloc(ctx, &ctx->d_wf_counts, 2);
+        int rc = dev_alloc(ctx, &ctx->d_wf_counts, 2 * WF_COUNT_WORDS);
         if (rc) return rc;
     }
     // carve: set 0 {a,b,c,d}, set 1 {a,b,c,d}, results
@@ -264,6 +271,7 @@ int launch_wavefront(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sam
     P.result = result;
     P.stats = reinterpret_cast<unsigned long long *>(ctx->d_queue + 2);
     const size_t lds_bytes = (size_t)ctx->n_surfaces * SHADE_STRIDE * sizeof(float);
+    std::vector<uint32_t> counts(WF_COUNT_WORDS);
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 32, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
@@ -272,25 +280,38 @@ int launch_wavefront(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sam
     for (uint32_t done = 0; done < spp;) {
         const uint32_t batch_spp = std::min(batch_spp_max, spp - done);
         const uint32_t n_paths = batch_spp * n_pixels;
+        const uint32_t n_groups = blocks_for(n_paths);
         P.first_sample = first_sample + done;
         P.n_paths = n_paths;
+        P.shard_cap = shard_cap_for(n_paths);
         P.in = sets[0];
-        hipLaunchKernelGGL(k_wf_generate, dim3(blocks_for(n_paths)), dim3(BLOCK), 0, ctx->stream, P);
+        hipLaunchKernelGGL(k_wf_generate, dim3(n_groups), dim3(BLOCK), 0, ctx->stream, P);
         HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_wf_counts, &n_paths, 4, hipMemcpyHostToDevice, ctx->stream));
-        uint32_t live = n_paths;
+        // initial live counts: region s holds workgroups s, s + WF_SHARDS, ...; the last workgroup may be partial
+        std::fill(counts.begin(), counts.end(), 0u);
+        for (uint32_t g = 0; g < n_groups; g++)
+            counts[(g % WF_SHARDS) * WF_COUNT_STRIDE] += std::min<uint32_t>(BLOCK, n_paths - g * BLOCK);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_wf_counts, counts.data(), WF_COUNT_WORDS * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         int cur = 0;
-        while (live > 0) {
+        for (;;) {
+            uint64_t live = 0;
+            uint32_t most = 0;
+            for (uint32_t sh = 0; sh < WF_SHARDS; sh++) {
+                live += counts[sh * WF_COUNT_STRIDE];
+                most = std::max(most, counts[sh * WF_COUNT_STRIDE]);
+            }
+            if (live == 0) break;
             P.in = sets[cur];
             P.out = sets[cur ^ 1];
-            P.n_in = ctx->d_wf_counts + cur;
-            P.n_out = ctx->d_wf_counts + (cur ^ 1);
-            HIP_TRY(ctx, hipMemsetAsync(P.n_out, 0, 4, ctx->stream));
-            hipLaunchKernelGGL(k_wf_bounce<FAST>, dim3(blocks_for(live)), dim3(BLOCK), lds_bytes, ctx->stream, P);
+            P.n_in = ctx->d_wf_counts + cur * WF_COUNT_WORDS;
+            P.n_out = ctx->d_wf_counts + (cur ^ 1) * WF_COUNT_WORDS;
+            HIP_TRY(ctx, hipMemsetAsync(P.n_out, 0, WF_COUNT_WORDS * 4, ctx->stream));
+            hipLaunchKernelGGL(k_wf_bounce<FAST>, dim3(blocks_for(most) * WF_SHARDS), dim3(BLOCK), lds_bytes, ctx->stream, P);
             HIP_TRY(ctx, hipGetLastError());
             segments += live;
             launches++;
-            HIP_TRY(ctx, hipMemcpyAsync(&live, P.n_out, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(counts.data(), P.n_out, WF_COUNT_WORDS * 4, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             cur ^= 1;
         }

@@ -310,6 +310,15 @@ k_reduce_slabs(const float *slabs, uint32_t n_chunks, size_t n, float *accum)
 // slot = sample_in_batch * n_pixels + pixel: where the path's radiance goes.
 struct WfArrays { float4 *a, *b, *c; uint4 *d; };
 
+// The arrays are cut into WF_SHARDS equal regions; workgroup g works on region
+// g % WF_SHARDS and appends its survivors to the same region of the other set,
+// through that region's own counter.  One counter for the whole queue would
+// serialise every wave of the launch on one word; 64 counters on 64 different
+// 128-byte lines take the adds in parallel.  A region never overflows: it
+// receives at most as many paths as were read from it.
+constexpr uint32_t WF_SHARDS = 64;
+constexpr uint32_t WF_COUNT_STRIDE = 32;     // uint32 words between two counters (128 bytes)
+
 struct WfParams {
     Camera cam;
     const float *geom, *shade;
@@ -319,9 +328,10 @@ struct WfParams {
     uint32_t first_sample;     // global number of the batch's first sample
     uint32_t n_pixels;
     uint32_t n_paths;          // generate: paths in the batch
+    uint32_t shard_cap;        // paths a region can hold (a multiple of BLOCK)
     WfArrays in, out;
-    const uint32_t *n_in;      // bounce: number of live paths in `in`
-    uint32_t *n_out;           // bounce: survivors appended to `out` (zeroed before the launch)
+    const uint32_t *n_in;      // bounce: live paths per region of `in` (WF_COUNT_STRIDE apart)
+    uint32_t *n_out;           // bounce: survivors per region of `out` (zeroed before the launch)
     float *result;             // radiance of finished paths, 3 floats per slot
     unsigned long long *stats; // [1] += segments re-evaluated directly
 };
@@ -334,6 +344,8 @@ PT_DEV void wf_store(const WfArrays &w, uint32_t i, const PathState &ps, uint32_
     w.d[i] = make_uint4(ps.rng.key, ps.rng.ctr, (uint32_t)ps.depth, slot);
 }
 
+// Path i of the batch starts in region (i / BLOCK) % WF_SHARDS, at the place
+// the same workgroup index reads in the first bounce.
 __global__ void __launch_bounds__(BLOCK)
 k_wf_generate(WfParams P)
 {
@@ -343,7 +355,8 @@ k_wf_generate(WfParams P)
     PathState ps;
     path_begin(ps, P.cam, rng_pixel(P.seed_mix, pixel), P.first_sample + s,
                (int)(pixel % (uint32_t)P.cam.width), (int)(pixel / (uint32_t)P.cam.width));
-    wf_store(P.in, i, ps, i);
+    const uint32_t shard = blockIdx.x % WF_SHARDS, local = blockIdx.x / WF_SHARDS;
+    wf_store(P.in, shard * P.shard_cap + local * BLOCK + threadIdx.x, ps, i);
 }
 
 template <bool FAST>
@@ -354,12 +367,15 @@ k_wf_bounce(WfParams P)
     for (int i = threadIdx.x; i < P.n_surfaces * SHADE_STRIDE; i += BLOCK)
         lds_shade[i] = P.shade[i];
     __syncthreads();
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    const bool live = i < *P.n_in;
+    const uint32_t shard = blockIdx.x % WF_SHARDS, local = blockIdx.x / WF_SHARDS;
+    const uint32_t k = local * BLOCK + threadIdx.x;          // position within the region
+    const bool live = k < P.n_in[shard * WF_COUNT_STRIDE];
+    const uint32_t region = shard * P.shard_cap;
     bool survives = false;
     PathState ps;
     uint32_t slot = 0;
     if (live) {
+        const uint32_t i = region + k;
         const float4 a = P.in.a[i], b = P.in.b[i], c = P.in.c[i];
         const uint4 d = P.in.d[i];
         ps.o = v3(a.x, a.y, a.z);
@@ -381,10 +397,11 @@ k_wf_bounce(WfParams P)
     const unsigned long long mask = __ballot(survives);
     if (mask) {
         const uint32_t lane = __lane_id();
+        const int first = __ffsll((long long)mask) - 1;
         uint32_t base = 0;
-        if (lane == (uint32_t)__ffsll((long long)mask) - 1u) base = atomicAdd(P.n_out, (uint32_t)__popcll(mask));
-        base = (uint32_t)__shfl((int)base, __ffsll((long long)mask) - 1);
-        if (survives) wf_store(P.out, base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), ps, slot);
+        if ((int)lane == first) base = atomicAdd(P.n_out + shard * WF_COUNT_STRIDE, (uint32_t)__popcll(mask));
+        base = (uint32_t)__shfl((int)base, first);
+        if (survives) wf_store(P.out, region + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), ps, slot);
     }
 }
 
