@@ -142,14 +142,14 @@ int check_ready(pt_ctx *ctx, bool need_camera)
     return use_device(ctx);
 }
 
-template <bool FAST>
+template <bool FAST, bool SHADE_LDS>
 int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample, uint64_t seed)
 {
     const uint32_t n_pixels = (uint32_t)ctx->cam.width * (uint32_t)ctx->cam.height;
-    const size_t lds_bytes = (size_t)ctx->n_surfaces * SHADE_STRIDE * sizeof(float);
+    const size_t lds_bytes = SHADE_LDS ? (size_t)ctx->n_surfaces * SHADE_STRIDE * sizeof(float) : 0;
 
     int blocks_per_cu = 0;
-    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_render_mega<FAST>, BLOCK, lds_bytes));
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, (k_render_mega<FAST, SHADE_LDS>), BLOCK, lds_bytes));
     if (blocks_per_cu < 1) return fail(ctx, PT_E_HIP, "render kernel does not fit on a compute unit");
     const uint32_t grid = (uint32_t)blocks_per_cu * (uint32_t)ctx->num_cus;
     const uint64_t lanes = (uint64_t)grid * BLOCK;
@@ -192,7 +192,7 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 32, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    hipLaunchKernelGGL(k_render_mega<FAST>, dim3(grid), dim3(BLOCK), lds_bytes, ctx->stream, P);
+    hipLaunchKernelGGL((k_render_mega<FAST, SHADE_LDS>), dim3(grid), dim3(BLOCK), lds_bytes, ctx->stream, P);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     const size_t n = (size_t)n_pixels * 3;
@@ -202,7 +202,7 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
 
     hipFuncAttributes attr{};
-    HIP_TRY(ctx, hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k_render_mega<FAST>)));
+    HIP_TRY(ctx, hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_render_mega<FAST, SHADE_LDS>)));
     ctx->last = pt_counters{};
     ctx->last.samples = (uint64_t)n_pixels * spp;
     ctx->last.vgprs = (uint32_t)attr.numRegs;
@@ -220,7 +220,7 @@ constexpr size_t WF_MAX_PATHS = 48u << 20;          // 48 Mi paths: 2 x 3 GiB of
 constexpr size_t WF_BYTES_PER_PATH = 2 * 64 + 12;
 constexpr size_t WF_COUNT_WORDS = (size_t)WF_SHARDS * WF_COUNT_STRIDE;
 
-template <bool FAST>
+template <bool FAST, bool SHADE_LDS>
 int launch_wavefront(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample, uint64_t seed)
 {
     const uint32_t n_pixels = (uint32_t)ctx->cam.width * (uint32_t)ctx->cam.height;
@@ -270,7 +270,7 @@ int launch_wavefront(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sam
     P.n_pixels = n_pixels;
     P.result = result;
     P.stats = reinterpret_cast<unsigned long long *>(ctx->d_queue + 2);
-    const size_t lds_bytes = (size_t)ctx->n_surfaces * SHADE_STRIDE * sizeof(float);
+    const size_t lds_bytes = SHADE_LDS ? (size_t)ctx->n_surfaces * SHADE_STRIDE * sizeof(float) : 0;
     std::vector<uint32_t> counts(WF_COUNT_WORDS);
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 32, ctx->stream));
@@ -307,7 +307,7 @@ int launch_wavefront(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sam
             P.n_in = ctx->d_wf_counts + cur * WF_COUNT_WORDS;
             P.n_out = ctx->d_wf_counts + (cur ^ 1) * WF_COUNT_WORDS;
             HIP_TRY(ctx, hipMemsetAsync(P.n_out, 0, WF_COUNT_WORDS * 4, ctx->stream));
-            hipLaunchKernelGGL(k_wf_bounce<FAST>, dim3(blocks_for(most) * WF_SHARDS), dim3(BLOCK), lds_bytes, ctx->stream, P);
+            hipLaunchKernelGGL((k_wf_bounce<FAST, SHADE_LDS>), dim3(blocks_for(most) * WF_SHARDS), dim3(BLOCK), lds_bytes, ctx->stream, P);
             HIP_TRY(ctx, hipGetLastError());
             segments += live;
             launches++;
@@ -328,7 +328,7 @@ int launch_wavefront(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sam
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 
     hipFuncAttributes attr{};
-    HIP_TRY(ctx, hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k_wf_bounce<FAST>)));
+    HIP_TRY(ctx, hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_wf_bounce<FAST, SHADE_LDS>)));
     ctx->last = pt_counters{};
     ctx->last.samples = (uint64_t)n_pixels * spp;
     ctx->last.vgprs = (uint32_t)attr.numRegs;
@@ -344,12 +344,17 @@ int render_dispatch(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_samp
     if ((uint64_t)first_sample + spp > 0xFFFFFFFFull)
         return fail(ctx, PT_E_LIMIT, "sample numbers must fit in 32 bits");
     if (mode & ~(PT_MODE_WAVEFRONT | PT_NUM_FAST)) return fail(ctx, PT_E_INVALID, "unknown mode bits 0x%x", mode);
+    const bool fast = (mode & PT_NUM_FAST) != 0, lds = ctx->n_surfaces <= MAX_LDS_SURFACES;
     if (mode & PT_MODE_WAVEFRONT) {
-        if (mode & PT_NUM_FAST) return launch_wavefront<true>(ctx, accum, spp, first_sample, seed);
-        return launch_wavefront<false>(ctx, accum, spp, first_sample, seed);
+        if (fast) return lds ? launch_wavefront<true, true>(ctx, accum, spp, first_sample, seed)
+                             : launch_wavefront<true, false>(ctx, accum, spp, first_sample, seed);
+        return lds ? launch_wavefront<false, true>(ctx, accum, spp, first_sample, seed)
+                   : launch_wavefront<false, false>(ctx, accum, spp, first_sample, seed);
     }
-    if (mode & PT_NUM_FAST) return launch_render<true>(ctx, accum, spp, first_sample, seed);
-    return launch_render<false>(ctx, accum, spp, first_sample, seed);
+    if (fast) return lds ? launch_render<true, true>(ctx, accum, spp, first_sample, seed)
+                         : launch_render<true, false>(ctx, accum, spp, first_sample, seed);
+    return lds ? launch_render<false, true>(ctx, accum, spp, first_sample, seed)
+               : launch_render<false, false>(ctx, accum, spp, first_sample, seed);
 }
 
 }  // namespace
@@ -422,9 +427,8 @@ int pt_set_scene(pt_ctx *ctx, const pt_surface *surfaces, int32_t n_surfaces,
     if (!ctx) return fail(nullptr, PT_E_INVALID, "null context");
     if (n_surfaces < 0 || n_materials < 0 || (n_surfaces > 0 && (!surfaces || !materials)) || !bg)
         return fail(ctx, PT_E_INVALID, "bad scene arguments");
-    const size_t lds_limit = 64 * 1024 / (SHADE_STRIDE * sizeof(float));
-    if ((size_t)n_surfaces > lds_limit)
-        return fail(ctx, PT_E_LIMIT, "%d surfaces exceed the %zu this build keeps in LDS", n_surfaces, lds_limit);
+    if (n_surfaces > (1 << 26))
+        return fail(ctx, PT_E_LIMIT, "%d surfaces exceed the maximum of %d", n_surfaces, 1 << 26);
     int rc = use_device(ctx);
     if (rc) return rc;
 

@@ -9,6 +9,7 @@ constexpr int BLOCK = 256;           // 4 waves of 64
 constexpr uint32_t POOL_BATCH = 64;  // work items a wave takes from the global queue at a time
 constexpr uint32_t NO_ITEM = 0xFFFFFFFFu;
 constexpr int MAX_DEPTH = 1024;      // PT_MAX_DEPTH
+constexpr int MAX_LDS_SURFACES = 64 * 1024 / (12 * 4);   // shading records kept in LDS (64 KiB)
 
 struct RenderParams {
     Camera cam;
@@ -160,9 +161,8 @@ PT_DEV bool path_segment(PathState &ps, cfloat_p geom, int n_surfaces, const flo
                     S::mad(bg[2], ps.thr.z, ps.col.z));
         return true;
     }
-    const float4 r0 = *reinterpret_cast<const float4 *>(shade + h.idx * SHADE_STRIDE);
-    const float4 r1 = *reinterpret_cast<const float4 *>(shade + h.idx * SHADE_STRIDE + 4);
-    const float4 r2 = *reinterpret_cast<const float4 *>(shade + h.idx * SHADE_STRIDE + 8);
+    const float4 *rec = reinterpret_cast<const float4 *>(shade + (size_t)h.idx * SHADE_STRIDE);
+    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
     const int flags = __builtin_bit_cast(int, r0.w);
     const int type = flags & 0xff;
     const V3 point = N::along(ps.o, ps.d, h.t);
@@ -202,14 +202,22 @@ PT_DEV bool path_segment(PathState &ps, cfloat_p geom, int n_surfaces, const flo
 // from a global counter, POOL_BATCH at a time per wave, and are handed to
 // lanes from a wave-uniform pool.  A lane leaves the loop when the queue is
 // empty: every wave reaches that state, so the grid always drains.
-template <bool FAST>
+//
+// SHADE_LDS: the shading records fit in LDS and are staged there once per
+// workgroup; otherwise (scenes above MAX_LDS_SURFACES) lanes read them from
+// global memory.
+template <bool FAST, bool SHADE_LDS>
 __global__ void __launch_bounds__(BLOCK)
 k_render_mega(RenderParams P)
 {
     extern __shared__ __align__(16) float lds_shade[];
-    for (int i = threadIdx.x; i < P.n_surfaces * SHADE_STRIDE; i += BLOCK)
-        lds_shade[i] = P.shade[i];
-    __syncthreads();
+    const float *shade = P.shade;
+    if constexpr (SHADE_LDS) {
+        for (int i = threadIdx.x; i < P.n_surfaces * SHADE_STRIDE; i += BLOCK)
+            lds_shade[i] = P.shade[i];
+        __syncthreads();
+        shade = lds_shade;
+    }
 
     const cfloat_p geom = as_constant(P.geom);
     const uint32_t lane = __lane_id();
@@ -277,7 +285,7 @@ k_render_mega(RenderParams P)
             path_begin(ps, P.cam, pixel_key, s, px, py);
             need_path = false;
         }
-        const bool ended = path_segment<FAST>(ps, geom, P.n_surfaces, lds_shade, P.bg, P.stats + 1);
+        const bool ended = path_segment<FAST>(ps, geom, P.n_surfaces, shade, P.bg, P.stats + 1);
         n_seg++;
         if (ended) {
             sum = sum + ps.col;                 // buffer[u][v] += color, main.cpp:139
@@ -359,14 +367,18 @@ k_wf_generate(WfParams P)
     wf_store(P.in, shard * P.shard_cap + local * BLOCK + threadIdx.x, ps, i);
 }
 
-template <bool FAST>
+template <bool FAST, bool SHADE_LDS>
 __global__ void __launch_bounds__(BLOCK)
 k_wf_bounce(WfParams P)
 {
     extern __shared__ __align__(16) float lds_shade[];
-    for (int i = threadIdx.x; i < P.n_surfaces * SHADE_STRIDE; i += BLOCK)
-        lds_shade[i] = P.shade[i];
-    __syncthreads();
+    const float *shade = P.shade;
+    if constexpr (SHADE_LDS) {
+        for (int i = threadIdx.x; i < P.n_surfaces * SHADE_STRIDE; i += BLOCK)
+            lds_shade[i] = P.shade[i];
+        __syncthreads();
+        shade = lds_shade;
+    }
     const uint32_t shard = blockIdx.x % WF_SHARDS, local = blockIdx.x / WF_SHARDS;
     const uint32_t k = local * BLOCK + threadIdx.x;          // position within the region
     const bool live = k < P.n_in[shard * WF_COUNT_STRIDE];
@@ -386,7 +398,7 @@ k_wf_bounce(WfParams P)
         ps.rng.ctr = d.y;
         ps.depth = (int)d.z;
         slot = d.w;
-        const bool ended = path_segment<FAST>(ps, as_constant(P.geom), P.n_surfaces, lds_shade, P.bg, P.stats + 1);
+        const bool ended = path_segment<FAST>(ps, as_constant(P.geom), P.n_surfaces, shade, P.bg, P.stats + 1);
         if (ended) {
             float *r = P.result + 3ull * slot;
             r[0] = ps.col.x; r[1] = ps.col.y; r[2] = ps.col.z;

@@ -6,9 +6,11 @@
 
 extern "C" {
 
-// Flattens built-in scene `name` for a width x height image (focal length =
-// height pixels).  surfaces/materials hold `capacity` entries.  Returns 0,
-// -1 for an unknown name, -2 if capacity is too small.
+// Flattens scene `name` (Scenes::by_name) for a width x height image (focal
+// length = height pixels).  surfaces/materials hold `capacity` entries.
+// Returns 0, -1 for an unknown name, -2 if capacity is too small; *n_surfaces
+// is set to the scene's size in both of the last two cases, so a caller can
+// size its arrays with a first call of capacity 0.
 int pt_host_builtin_scene(const char *name, int width, int height, pt_surface *surfaces,
                           pt_material *materials, int32_t capacity, int32_t *n_surfaces,
                           float bg[3], pt_camera *camera)
@@ -17,7 +19,8 @@ int pt_host_builtin_scene(const char *name, int width, int height, pt_surface *s
     std::optional<Scene> scene;
     if (!Scenes::by_name(name, scene)) return -1;
     const pt::FlatScene flat = pt::flatten(*scene, width, height);
-    if (static_cast<int32_t>(flat.surfaces.size()) > capacity) return -2;
+    *n_surfaces = static_cast<int32_t>(flat.surfaces.size());
+    if (*n_surfaces > capacity) return -2;
     for (size_t i = 0; i < flat.surfaces.size(); i++) {
         surfaces[i] = flat.surfaces[i];
         materials[i] = flat.materials[i];

@@ -4,6 +4,9 @@
 // focal length of SCREEN_HEIGHT pixels and the constructor that adds OFFSET.
 #pragma once
 
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 #include "pt_types.hpp"
@@ -145,7 +148,106 @@ inline Scene cornell()
     return finish(s, vec3(0, 0, -3), vec2(0, 0), 0.1f * vec3(1, 1, 1), false);
 }
 
-// Looks a built-in scene up by name; returns false for an unknown name.
+// ---- synthetic stress scenes (not in the reference; built from its types) ----
+
+namespace detail {
+
+inline uint32_t hash32(uint32_t v)
+{
+    uint32_t s = v * 747796405u + 2891336453u;
+    uint32_t w = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
+    return (w >> 22) ^ w;
+}
+// uniform in [0,1) from an integer key
+inline float hash01(uint32_t key) { return static_cast<float>(hash32(key) >> 8) * (1.0f / 16777216.0f); }
+
+// smooth value noise on the integer lattice, in [0,1)
+inline float value_noise(float x, float z, uint32_t seed)
+{
+    const float fx = std::floor(x), fz = std::floor(z);
+    const int ix = static_cast<int>(fx), iz = static_cast<int>(fz);
+    const float tx = x - fx, tz = z - fz;
+    const float sx = tx * tx * (3 - 2 * tx), sz = tz * tz * (3 - 2 * tz);
+    auto corner = [&](int cx, int cz) {
+        return hash01(seed ^ (static_cast<uint32_t>(cx) * 0x9E3779B1u) ^ (static_cast<uint32_t>(cz) * 0x85EBCA77u));
+    };
+    const float a = corner(ix, iz), b = corner(ix + 1, iz), c = corner(ix, iz + 1), d = corner(ix + 1, iz + 1);
+    return (a + (b - a) * sx) + ((c + (d - c) * sx) - (a + (b - a) * sx)) * sz;
+}
+
+}  // namespace detail
+
+// Glass-heavy stress scene: the cornell_2 walls and sphere light, a 5 x 5 x 3
+// lattice of glass spheres (radius 0.12, positions jittered by a hash of seed 4)
+// and four mirror spheres.  Mirror and glass leave the throughput at 1, so
+// russian roulette keeps paths alive at its 0.95 cap: long paths, divergent
+// materials.
+inline Scene glass_stress()
+{
+    using namespace detail;
+    SurfaceList s;
+    cornell_walls(s, diffuse(1.00f, 0.05f, 0.05f), diffuse(1, 0.05f, 1), diffuse(1, 1, 0.05f),
+                  diffuse(0.05f, 1, 1), diffuse(1, 1, 1));
+    add_surface(s, Sphere(vec3(0, -1.8, 0), 1, diffuse(1, 1, 1, 2.0f)));
+    const uint32_t seed = 4;
+    for (int k = 0; k < 3; k++)
+        for (int j = 0; j < 5; j++)
+            for (int i = 0; i < 5; i++) {
+                const uint32_t id = static_cast<uint32_t>((k * 5 + j) * 5 + i);
+                const float jx = (hash01(seed * 1000003u + 3 * id) - 0.5f) * 0.08f;
+                const float jy = (hash01(seed * 1000003u + 3 * id + 1) - 0.5f) * 0.08f;
+                const float jz = (hash01(seed * 1000003u + 3 * id + 2) - 0.5f) * 0.08f;
+                const vec3 c(-0.72f + 0.36f * i + jx, -0.45f + 0.33f * j + jy, -0.55f + 0.5f * k + jz);
+                add_surface(s, Sphere(c, 0.12f, Material(GLASS)));
+            }
+    const float m[4][3] = {{-0.75f, 0.8f, 0.7f}, {0.75f, 0.8f, 0.7f}, {-0.75f, -0.6f, 0.75f}, {0.75f, -0.6f, 0.75f}};
+    for (const auto &c : m) add_surface(s, Sphere(vec3(c[0], c[1], c[2]), 0.2f, Material(MIRROR)));
+    return finish(s, vec3(0, 0, -3), vec2(0, 0), 0.0f * vec3(1, 1, 1), false);
+}
+
+// Large-mesh scene: cornell_2 with its floor triangle replaced by a height
+// field of quads x quads cells (two triangles each; 707 gives 999,698
+// triangles) over x,z in [-1,1], heights 0.15 * value noise above y = 1 (y is
+// down), per-triangle diffuse colours from a hash of seed 5.  Winding is chosen
+// so that normalize(cross(v2-v0, v1-v0)) points up (-y).
+inline Scene heightfield_mesh(int quads = 707)
+{
+    using namespace detail;
+    SurfaceList s;
+    s.reserve(static_cast<size_t>(quads) * quads * 2 + 8);
+    const uint32_t seed = 5;
+    auto height = [&](int i, int k) {
+        const float x = 8.0f * i / quads, z = 8.0f * k / quads;
+        return 1.0f - 0.15f * value_noise(x, z, seed);
+    };
+    auto vertex = [&](int i, int k) {
+        return vec3(-1.0f + 2.0f * i / quads, height(i, k), -1.0f + 2.0f * k / quads);
+    };
+    for (int k = 0; k < quads; k++)
+        for (int i = 0; i < quads; i++) {
+            const vec3 p00 = vertex(i, k), p10 = vertex(i + 1, k), p01 = vertex(i, k + 1), p11 = vertex(i + 1, k + 1);
+            const uint32_t id = static_cast<uint32_t>(k * quads + i);
+            const Material m0 = diffuse(0.3f + 0.7f * hash01(seed + 6 * id), 0.3f + 0.7f * hash01(seed + 6 * id + 1),
+                                        0.3f + 0.7f * hash01(seed + 6 * id + 2));
+            const Material m1 = diffuse(0.3f + 0.7f * hash01(seed + 6 * id + 3), 0.3f + 0.7f * hash01(seed + 6 * id + 4),
+                                        0.3f + 0.7f * hash01(seed + 6 * id + 5));
+            // v1 along +z, v2 along +x: cross(v2-v0, v1-v0) = (+x) x (+z) = -y, up
+            add_surface(s, Triangle(p00, p01, p10, m0));
+            add_surface(s, Triangle(p10, p01, p11, m1));
+        }
+    add_surface(s, Triangle(vec3(-1, -2, -1), vec3(-1, 0, 10), vec3(-1, 2, -1), diffuse(1, 0.05f, 1)));
+    add_surface(s, Triangle(vec3(1, -2, -1), vec3(1, 2, -1), vec3(1, 0, 10), diffuse(1, 1, 0.05f)));
+    add_surface(s, Triangle(vec3(-2, -1, -1), vec3(2, -1, -1), vec3(0, -1, 10), diffuse(0.05f, 1, 1)));
+    add_surface(s, Triangle(vec3(-2, 1, 1), vec3(0, -10, 1), vec3(2, 1, 1), diffuse(1, 1, 1)));
+    add_surface(s, Sphere(vec3(-0.32, 0.6, 0.26), 0.4, Material(MIRROR)));
+    add_surface(s, Sphere(vec3(0.35, 0.6, -0.39), 0.4, Material(GLASS)));
+    add_surface(s, Sphere(vec3(0, -1.8, 0), 1, diffuse(1, 1, 1, 2.0f)));
+    return finish(s, vec3(0, 0, -3), vec2(0, 0), 0.0f * vec3(1, 1, 1), false);
+}
+
+// Looks a scene up by name: the reference's seven, "glass_stress", and
+// "heightfield" or "heightfield:<quads per side>".  Returns false for an
+// unknown name.
 inline bool by_name(const char *name, std::optional<Scene> &out)
 {
     struct Entry { const char *name; Scene (*make)(); };
@@ -154,6 +256,14 @@ inline bool by_name(const char *name, std::optional<Scene> &out)
                                   {"cornell_2", cornell_2}, {"cornell", cornell}};
     for (const Entry &e : table)
         if (!std::strcmp(e.name, name)) { out.emplace(e.make()); return true; }
+    if (!std::strcmp(name, "glass_stress")) { out.emplace(glass_stress()); return true; }
+    if (!std::strcmp(name, "heightfield")) { out.emplace(heightfield_mesh()); return true; }
+    if (!std::strncmp(name, "heightfield:", 12)) {
+        const int quads = std::atoi(name + 12);
+        if (quads < 1 || quads > 4000) return false;
+        out.emplace(heightfield_mesh(quads));
+        return true;
+    }
     return false;
 }
 

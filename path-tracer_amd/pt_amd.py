@@ -120,19 +120,24 @@ class SceneData:
 
 
 def builtin_scene(name, width, height):
-    """One of the reference's Scenes::* (src/scene.hpp:32-203) from the C++ host mirror,
-    flattened, with focal length = height as every built-in scene has."""
+    """A scene of the C++ host mirror by name, flattened, with focal length = height:
+    one of the reference's Scenes::* (src/scene.hpp:32-203), "glass_stress", or
+    "heightfield[:quads]"."""
     host = load_host()
-    surf = np.zeros(64, dtype=SURFACE)
-    mats = np.zeros(64, dtype=MATERIAL)
     bg = np.zeros(3, dtype=np.float32)
     cam = np.zeros(1, dtype=CAMERA)
     n = C.c_int32(0)
+    rc = host.pt_host_builtin_scene(name.encode(), int(width), int(height), None, None,
+                                    C.c_int32(0), C.byref(n), _p(bg), _p(cam))
+    if rc == -1:
+        raise KeyError("unknown scene %r" % name)
+    surf = np.zeros(max(n.value, 1), dtype=SURFACE)
+    mats = np.zeros(max(n.value, 1), dtype=MATERIAL)
     rc = host.pt_host_builtin_scene(name.encode(), int(width), int(height), _p(surf), _p(mats),
-                                    C.c_int32(64), C.byref(n), _p(bg), _p(cam))
+                                    C.c_int32(len(surf)), C.byref(n), _p(bg), _p(cam))
     if rc != 0:
-        raise KeyError("unknown built-in scene %r" % name)
-    return SceneData(surf[:n.value].copy(), mats[:n.value].copy(), bg, cam)
+        raise RuntimeError("pt_host_builtin_scene(%r) failed with %d" % (name, rc))
+    return SceneData(surf[:n.value], mats[:n.value], bg, cam)
 
 
 class Context:

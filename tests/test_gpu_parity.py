@@ -366,3 +366,68 @@ def test_wavefront_equals_megakernel(ctx, pt, name):
     fast, cf = render(ctx, pt, sc, 20, first=7, seed=3, mode=pt.MODE_WAVEFRONT | pt.NUM_FAST)
     assert abs(int(cf.segments) - int(cm.segments)) < 0.01 * cm.segments
     assert np.allclose(fast.mean((0, 1)), mega.mean((0, 1)), rtol=0.02)
+
+
+# ---------------------------------------------------------------- synthetic stress scenes
+
+def as_oracle_scene(orc, sc):
+    return orc.Scene(sc.surfaces.view(orc.SURFACE), sc.materials.view(orc.MATERIAL), sc.bg,
+                     sc.camera.view(orc.CAMERA))
+
+
+def test_glass_stress_scene(ctx, pt, orc):
+    """Deep mirror/glass paths (russian roulette at its 0.95 cap): bit-exact primary hits,
+    path-matched image, long paths present."""
+    sc = pt.builtin_scene("glass_stress", 160, 90)
+    assert sc.n_spheres == 80 and sc.n_triangles == 5
+    osc = as_oracle_scene(orc, sc)
+    load(ctx, sc)
+    idx, dist = ctx.primary_hits()
+    oidx, odist = orc.primary_hits(osc)
+    assert np.array_equal(idx, oidx) and np.array_equal(dist, odist)
+    acc, cnt = render(ctx, pt, sc, 4, seed=4)
+    oacc, ocnt = orc.render(osc, 4, seed=4, threads=8)
+    frac = np.isclose(acc, oacc, rtol=2e-3, atol=2e-3).all(axis=2).mean()
+    print("glass_stress: %.4f of pixels match; %.2f segments/sample (oracle %.2f, longest %d)" % (
+        frac, cnt.segments / cnt.samples, ocnt.segments / ocnt.samples, ocnt.max_depth))
+    assert frac >= 0.95
+    assert abs(cnt.segments - ocnt.segments) <= 0.01 * ocnt.segments
+    assert cnt.segments / cnt.samples > 5.5
+
+
+def test_large_mesh_scene_beyond_lds(ctx, pt, orc):
+    """3207 surfaces: shading records no longer fit in LDS and are read from global memory."""
+    sc = pt.builtin_scene("heightfield:40", 96, 96)
+    assert len(sc.surfaces) == 2 * 40 * 40 + 7
+    osc = as_oracle_scene(orc, sc)
+    load(ctx, sc)
+    idx, dist = ctx.primary_hits()
+    oidx, odist = orc.primary_hits(osc)
+    assert np.array_equal(idx, oidx) and np.array_equal(dist, odist)
+    assert len(np.unique(idx)) > 500
+    rng = np.random.default_rng(2)
+    o, d = random_rays(rng, 20000, 1.0)
+    o[:, 1] -= 0.5
+    got = ctx.intersect_rays(o, d)
+    want = orc.intersect_rays(osc, o, d)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    for mode in (pt.MODE_MEGAKERNEL, pt.MODE_WAVEFRONT):
+        acc, cnt = render(ctx, pt, sc, 2, seed=6, mode=mode)
+        oacc, ocnt = orc.render(osc, 2, seed=6, threads=8)
+        frac = np.isclose(acc, oacc, rtol=2e-3, atol=2e-3).all(axis=2).mean()
+        print("heightfield:40 mode %d: %.4f of pixels match" % (mode, frac))
+        assert frac >= 0.97
+        assert abs(cnt.segments - ocnt.segments) <= 0.01 * ocnt.segments
+
+
+def test_million_triangle_scene_primary_hits(ctx, pt, orc):
+    """The full 999,698-triangle height field (plus 7 other surfaces), brute force, on a
+    16 x 16 image: bit-exact against the oracle."""
+    sc = pt.builtin_scene("heightfield", 16, 16)
+    assert len(sc.surfaces) == 999705 and sc.n_triangles == 999702
+    load(ctx, sc)
+    idx, dist = ctx.primary_hits()
+    oidx, odist = orc.primary_hits(as_oracle_scene(orc, sc))
+    assert np.array_equal(idx, oidx) and np.array_equal(dist, odist)
+    assert (idx >= 0).all() and len(np.unique(idx)) > 100
