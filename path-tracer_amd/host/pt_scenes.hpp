@@ -207,21 +207,22 @@ inline Scene glass_stress()
 
 // Large-mesh scene: cornell_2 with its floor triangle replaced by a height
 // field of quads x quads cells (two triangles each; 707 gives 999,698
-// triangles) over x,z in [-1,1], heights 0.15 * value noise above y = 1 (y is
-// down), per-triangle diffuse colours from a hash of seed 5.  Winding is chosen
-// so that normalize(cross(v2-v0, v1-v0)) points up (-y).
+// triangles), heights up to 0.15 above y = 1 (y is down) from value noise,
+// per-triangle diffuse colours from a hash of seed 5.  Cells are 0.03 wide
+// whatever their number, so the field spreads beyond the box: the reference's
+// triangle test rejects |determinant| < 1e-5 (src/surface.hpp:53), which is
+// twice the projected area of the triangle, so much smaller cells would never
+// be hit.  Winding is chosen so that normalize(cross(v2-v0, v1-v0)) points up.
 inline Scene heightfield_mesh(int quads = 707)
 {
     using namespace detail;
     SurfaceList s;
     s.reserve(static_cast<size_t>(quads) * quads * 2 + 8);
     const uint32_t seed = 5;
-    auto height = [&](int i, int k) {
-        const float x = 8.0f * i / quads, z = 8.0f * k / quads;
-        return 1.0f - 0.15f * value_noise(x, z, seed);
-    };
+    const float cell = 0.03f, x0 = -0.5f * cell * quads, z0 = -1.0f;
     auto vertex = [&](int i, int k) {
-        return vec3(-1.0f + 2.0f * i / quads, height(i, k), -1.0f + 2.0f * k / quads);
+        const float x = x0 + cell * i, z = z0 + cell * k;
+        return vec3(x, 1.0f - 0.15f * value_noise(4.0f * x, 4.0f * z, seed), z);
     };
     for (int k = 0; k < quads; k++)
         for (int i = 0; i < quads; i++) {
