@@ -46,6 +46,11 @@ extern "C" {
 /* One Surface, in scene order (Scene::surfaces, src/scene.hpp:18).
  * Triangle (src/surface.hpp:33-35): a,b,c = v0,v1,v2.
  * Sphere   (src/surface.hpp:78-79): a = position, b[0] = radius. */
+/* pt_set_accel modes */
+#define PT_ACCEL_AUTO 0   /* hierarchy when the scene has 256 triangles or more */
+#define PT_ACCEL_NONE 1   /* always the reference's linear scan over every surface */
+#define PT_ACCEL_BVH  2   /* hierarchy whenever the scene has two small triangles or more */
+
 typedef struct pt_surface {
     int32_t kind;        /* PT_TRIANGLE | PT_SPHERE */
     int32_t material;    /* index into the material table */
@@ -111,6 +116,13 @@ int pt_set_stream(pt_ctx *ctx, void *hip_stream);
 int pt_set_scene(pt_ctx *ctx, const pt_surface *surfaces, int32_t n_surfaces,
                  const pt_material *materials, int32_t n_materials, const float bg[3]);
 
+/* Chooses how the closest hit is searched; rebuilds for the current scene.
+ * The reference scans every surface for every segment (src/main.cpp:58-66;
+ * an "octree" is a to-do note, src/main.cpp:75).  The hierarchy, built on the
+ * GPU over the scene's small triangles, returns the same surface, t and
+ * distance as the scan, ties included. */
+int pt_set_accel(pt_ctx *ctx, int accel);
+
 /* Uploads the camera and DOF state; (re)allocates the accumulation buffer
  * when the image size changes and clears it, as src/main.cpp:262-269 does
  * when the camera moved. */
@@ -150,18 +162,18 @@ int pt_write_accum(pt_ctx *ctx, const float *rgb_sum_host, uint64_t total_sample
  * out_host: height*width*3 bytes. */
 int pt_tonemap_rgb8(pt_ctx *ctx, uint8_t *out_host);
 
-/* Parity entry points (EXACT arithmetic).  Host pointers. */
+/* Parity entry points.  Host pointers.  numeric = PT_NUM_EXACT | PT_NUM_FAST. */
 
 /* get_ray_direction_by_pixel (src/main.cpp:50-54) on integer pixel corners,
  * then closest_intersection (src/main.cpp:56-67).  surf_idx[v*W+u] = index in
  * scene order or -1; distance = Intersection::distance (0 on a miss). */
-int pt_primary_hits(pt_ctx *ctx, int32_t *surf_idx, float *distance);
+int pt_primary_hits(pt_ctx *ctx, int32_t *surf_idx, float *distance, int numeric);
 
 /* closest_intersection (src/main.cpp:56-67) with Triangle::intersects
  * (src/surface.hpp:47-73) and Sphere::intersects (src/surface.hpp:91-112) on
  * caller-supplied rays.  origin, dir, point: n x 3 floats. */
 int pt_intersect_rays(pt_ctx *ctx, const float *origin, const float *dir, int64_t n,
-                      int32_t *surf_idx, float *distance, float *point);
+                      int32_t *surf_idx, float *distance, float *point, int numeric);
 
 /* The ray set-up of trace_rays (src/main.cpp:120-136) with forced random
  * numbers.  px: n x 2 (u,v); xi: n x 4 = jitter u, jitter v, lens radius

@@ -6,6 +6,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstring>   // rocprim uses memset without including it
+#include <rocprim/rocprim.hpp>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -56,6 +59,14 @@ struct pt_ctx {
     float bg[3] = {0, 0, 0};
     Camera cam{};
     float *d_geom = nullptr, *d_shade = nullptr;
+
+    // hierarchy over the small triangles (n_bvh == 0: none) and the surfaces left outside it
+    int accel = PT_ACCEL_AUTO;
+    int n_bvh = 0, n_loose = 0;
+    int *d_loose = nullptr;
+    std::vector<pt_surface> host_surfaces;      // kept to rebuild when pt_set_accel changes
+    float4 *d_bvh_nodes = nullptr;
+    float *d_bvh_leaves = nullptr;
 
     float *d_accum = nullptr;        // height*width*3 running sums
     size_t accum_floats = 0;
@@ -142,14 +153,154 @@ int check_ready(pt_ctx *ctx, bool need_camera)
     return use_device(ctx);
 }
 
-template <bool FAST, bool SHADE_LDS>
+// Builds the hierarchy over the scene's small triangles on the GPU, or clears
+// it when the scene has too few of them (or PT_ACCEL_NONE is set).  geom is
+// the host copy of the geometry records already uploaded to ctx->d_geom.
+constexpr int BVH_AUTO_MIN_TRIANGLES = 256;
+
+int build_hierarchy(pt_ctx *ctx, const pt_surface *surfaces, int n_surfaces)
+{
+    if (ctx->d_loose) (void)hipFree(ctx->d_loose);
+    if (ctx->d_bvh_nodes) (void)hipFree(ctx->d_bvh_nodes);
+    if (ctx->d_bvh_leaves) (void)hipFree(ctx->d_bvh_leaves);
+    ctx->d_loose = nullptr;
+    ctx->d_bvh_nodes = nullptr;
+    ctx->d_bvh_leaves = nullptr;
+    ctx->n_bvh = ctx->n_loose = 0;
+    if (ctx->accel == PT_ACCEL_NONE) return PT_OK;
+    if (ctx->accel == PT_ACCEL_AUTO && ctx->n_tri < BVH_AUTO_MIN_TRIANGLES) return PT_OK;
+
+    // bounds of the triangle centroids; a triangle much larger than that spread stays outside
+    float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = 0; i < n_surfaces; i++) {
+        if (surfaces[i].kind != PT_TRIANGLE) continue;
+        for (int k = 0; k < 3; k++) {
+            const float c = (surfaces[i].a[k] + surfaces[i].b[k] + surfaces[i].c[k]) / 3.0f;
+            cmin[k] = std::min(cmin[k], c);
+            cmax[k] = std::max(cmax[k], c);
+        }
+    }
+    const float spread = (cmax[0] - cmin[0]) + (cmax[1] - cmin[1]) + (cmax[2] - cmin[2]);
+    std::vector<int> loose, inside;
+    for (int i = 0; i < n_surfaces; i++) {
+        bool in = surfaces[i].kind == PT_TRIANGLE;
+        if (in) {
+            float size = 0;
+            for (int k = 0; k < 3; k++) {
+                const float lo = std::min({surfaces[i].a[k], surfaces[i].b[k], surfaces[i].c[k]});
+                const float hi = std::max({surfaces[i].a[k], surfaces[i].b[k], surfaces[i].c[k]});
+                size += hi - lo;
+            }
+            in = std::isfinite(size) && size <= 0.1f * spread;
+        }
+        (in ? inside : loose).push_back(i);
+    }
+    const int n = (int)inside.size();
+    if (n < 2) return PT_OK;
+
+    // centroid bounds of the triangles that go in, for the Morton grid
+    for (int k = 0; k < 3; k++) { cmin[k] = INFINITY; cmax[k] = -INFINITY; }
+    for (int i : inside)
+        for (int k = 0; k < 3; k++) {
+            const float lo = std::min({surfaces[i].a[k], surfaces[i].b[k], surfaces[i].c[k]});
+            const float hi = std::max({surfaces[i].a[k], surfaces[i].b[k], surfaces[i].c[k]});
+            cmin[k] = std::min(cmin[k], 0.5f * (lo + hi));
+            cmax[k] = std::max(cmax[k], 0.5f * (lo + hi));
+        }
+    float3 gmin = make_float3(cmin[0], cmin[1], cmin[2]), ginv;
+    ginv.x = cmax[0] > cmin[0] ? 1.0f / (cmax[0] - cmin[0]) : 0.0f;
+    ginv.y = cmax[1] > cmin[1] ? 1.0f / (cmax[1] - cmin[1]) : 0.0f;
+    ginv.z = cmax[2] > cmin[2] ? 1.0f / (cmax[2] - cmin[2]) : 0.0f;
+
+    int rc;
+    Scratch<int> d_inside, d_parent_node, d_parent_leaf;
+    Scratch<unsigned long long> d_keys, d_sorted;
+    Scratch<float4> d_bmin, d_bmax;
+    Scratch<int2> d_children;
+    Scratch<unsigned int> d_arrivals;
+    Scratch<char> d_temp;
+    if ((rc = upload(ctx, d_inside, inside.data(), (size_t)n))) return rc;
+    if ((rc = dev_alloc(ctx, &d_keys.p, (size_t)n))) return rc;
+    if ((rc = dev_alloc(ctx, &d_sorted.p, (size_t)n))) return rc;
+    if ((rc = dev_alloc(ctx, &d_bmin.p, (size_t)n))) return rc;
+    if ((rc = dev_alloc(ctx, &d_bmax.p, (size_t)n))) return rc;
+    if ((rc = dev_alloc(ctx, &d_children.p, (size_t)n))) return rc;
+    if ((rc = dev_alloc(ctx, &d_parent_node.p, (size_t)n))) return rc;
+    if ((rc = dev_alloc(ctx, &d_parent_leaf.p, (size_t)n))) return rc;
+    if ((rc = dev_alloc(ctx, &d_arrivals.p, (size_t)n))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_bvh_nodes, (size_t)n * BVH_NODE_QUADS))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_bvh_leaves, (size_t)n * GEOM_STRIDE))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_loose, std::max<size_t>(loose.size(), 1)))) return rc;
+    if (!loose.empty())
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_loose, loose.data(), loose.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_bvh_prepare, dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_geom, d_inside.p, n, gmin, ginv,
+                       d_keys.p, d_bmin.p, d_bmax.p);
+    HIP_TRY(ctx, hipGetLastError());
+    size_t temp_bytes = 0;
+    HIP_TRY(ctx, rocprim::radix_sort_keys(nullptr, temp_bytes, d_keys.p, d_sorted.p, (size_t)n, 0, 64, ctx->stream));
+    if ((rc = dev_alloc(ctx, &d_temp.p, std::max<size_t>(temp_bytes, 1)))) return rc;
+    HIP_TRY(ctx, rocprim::radix_sort_keys(d_temp.p, temp_bytes, d_keys.p, d_sorted.p, (size_t)n, 0, 64, ctx->stream));
+    hipLaunchKernelGGL(k_bvh_hierarchy, dim3(blocks), dim3(256), 0, ctx->stream, d_sorted.p, n, d_children.p,
+                       d_parent_node.p, d_parent_leaf.p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemsetAsync(d_arrivals.p, 0, (size_t)n * sizeof(unsigned int), ctx->stream));
+    hipLaunchKernelGGL(k_bvh_refit, dim3(blocks), dim3(256), 0, ctx->stream, d_sorted.p, n, d_children.p,
+                       d_parent_node.p, d_parent_leaf.p, d_bmin.p, d_bmax.p, d_arrivals.p, ctx->d_bvh_nodes);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_bvh_leaves, dim3(blocks), dim3(256), 0, ctx->stream, d_sorted.p, n, ctx->d_geom, d_inside.p,
+                       ctx->d_bvh_leaves);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_bvh = n;
+    ctx->n_loose = (int)loose.size();
+    return PT_OK;
+}
+
+SceneView scene_view(const pt_ctx *ctx)
+{
+    SceneView v{};
+    v.geom = ctx->d_geom;
+    v.shade = ctx->d_shade;
+    v.n_surfaces = ctx->n_surfaces;
+    v.n_scan = ctx->n_bvh > 0 ? ctx->n_loose : ctx->n_surfaces;
+    v.loose = ctx->d_loose;
+    v.bvh.nodes = ctx->d_bvh_nodes;
+    v.bvh.leaves = ctx->d_bvh_leaves;
+    v.bvh.n_leaves = ctx->n_bvh;
+    memcpy(v.bg, ctx->bg, sizeof v.bg);
+    return v;
+}
+
+int scene_kind(const pt_ctx *ctx)
+{
+    if (ctx->n_bvh > 0) return SCENE_BVH;
+    return ctx->n_surfaces <= MAX_LDS_SURFACES ? SCENE_LDS : SCENE_GLOBAL;
+}
+
+// Calls f.template operator()<FAST, KIND>() for the run-time numeric mode and scene kind.
+template <class F>
+int with_variant(bool fast, int kind, F &&f)
+{
+    if (fast) {
+        if (kind == SCENE_LDS) return f.template operator()<true, SCENE_LDS>();
+        if (kind == SCENE_GLOBAL) return f.template operator()<true, SCENE_GLOBAL>();
+        return f.template operator()<true, SCENE_BVH>();
+    }
+    if (kind == SCENE_LDS) return f.template operator()<false, SCENE_LDS>();
+    if (kind == SCENE_GLOBAL) return f.template operator()<false, SCENE_GLOBAL>();
+    return f.template operator()<false, SCENE_BVH>();
+}
+
+template <bool FAST, int KIND>
 int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample, uint64_t seed)
 {
     const uint32_t n_pixels = (uint32_t)ctx->cam.width * (uint32_t)ctx->cam.height;
-    const size_t lds_bytes = SHADE_LDS ? (size_t)ctx->n_surfaces * SHADE_STRIDE * sizeof(float) : 0;
+    const size_t lds_bytes = KIND == SCENE_LDS ? (size_t)ctx->n_surfaces * SHADE_STRIDE * sizeof(float) : 0;
 
     int blocks_per_cu = 0;
-    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, (k_render_mega<FAST, SHADE_LDS>), BLOCK, lds_bytes));
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, (k_render_mega<FAST, KIND>), BLOCK, lds_bytes));
     if (blocks_per_cu < 1) return fail(ctx, PT_E_HIP, "render kernel does not fit on a compute unit");
     const uint32_t grid = (uint32_t)blocks_per_cu * (uint32_t)ctx->num_cus;
     const uint64_t lanes = (uint64_t)grid * BLOCK;
@@ -176,10 +327,7 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
 
     RenderParams P{};
     P.cam = ctx->cam;
-    P.geom = ctx->d_geom;
-    P.shade = ctx->d_shade;
-    P.n_surfaces = ctx->n_surfaces;
-    memcpy(P.bg, ctx->bg, sizeof P.bg);
+    P.scene = scene_view(ctx);
     P.seed_mix = host_seed_mix(seed);
     P.first_sample = first_sample;
     P.spp = spp;
@@ -192,7 +340,7 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 32, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    hipLaunchKernelGGL((k_render_mega<FAST, SHADE_LDS>), dim3(grid), dim3(BLOCK), lds_bytes, ctx->stream, P);
+    hipLaunchKernelGGL((k_render_mega<FAST, KIND>), dim3(grid), dim3(BLOCK), lds_bytes, ctx->stream, P);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     const size_t n = (size_t)n_pixels * 3;
@@ -202,7 +350,7 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
 
     hipFuncAttributes attr{};
-    HIP_TRY(ctx, hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_render_mega<FAST, SHADE_LDS>)));
+    HIP_TRY(ctx, hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_render_mega<FAST, KIND>)));
     ctx->last = pt_counters{};
     ctx->last.samples = (uint64_t)n_pixels * spp;
     ctx->last.vgprs = (uint32_t)attr.numRegs;
@@ -220,7 +368,7 @@ constexpr size_t WF_MAX_PATHS = 48u << 20;          // 48 Mi paths: 2 x 3 GiB of
 constexpr size_t WF_BYTES_PER_PATH = 2 * 64 + 12;
 constexpr size_t WF_COUNT_WORDS = (size_t)WF_SHARDS * WF_COUNT_STRIDE;
 
-template <bool FAST, bool SHADE_LDS>
+template <bool FAST, int KIND>
 int launch_wavefront(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample, uint64_t seed)
 {
     const uint32_t n_pixels = (uint32_t)ctx->cam.width * (uint32_t)ctx->cam.height;
@@ -262,15 +410,12 @@ int launch_wavefront(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sam
 
     WfParams P{};
     P.cam = ctx->cam;
-    P.geom = ctx->d_geom;
-    P.shade = ctx->d_shade;
-    P.n_surfaces = ctx->n_surfaces;
-    memcpy(P.bg, ctx->bg, sizeof P.bg);
+    P.scene = scene_view(ctx);
     P.seed_mix = host_seed_mix(seed);
     P.n_pixels = n_pixels;
     P.result = result;
     P.stats = reinterpret_cast<unsigned long long *>(ctx->d_queue + 2);
-    const size_t lds_bytes = SHADE_LDS ? (size_t)ctx->n_surfaces * SHADE_STRIDE * sizeof(float) : 0;
+    const size_t lds_bytes = KIND == SCENE_LDS ? (size_t)ctx->n_surfaces * SHADE_STRIDE * sizeof(float) : 0;
     std::vector<uint32_t> counts(WF_COUNT_WORDS);
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 32, ctx->stream));
@@ -307,7 +452,7 @@ int launch_wavefront(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sam
             P.n_in = ctx->d_wf_counts + cur * WF_COUNT_WORDS;
             P.n_out = ctx->d_wf_counts + (cur ^ 1) * WF_COUNT_WORDS;
             HIP_TRY(ctx, hipMemsetAsync(P.n_out, 0, WF_COUNT_WORDS * 4, ctx->stream));
-            hipLaunchKernelGGL((k_wf_bounce<FAST, SHADE_LDS>), dim3(blocks_for(most) * WF_SHARDS), dim3(BLOCK), lds_bytes, ctx->stream, P);
+            hipLaunchKernelGGL((k_wf_bounce<FAST, KIND>), dim3(blocks_for(most) * WF_SHARDS), dim3(BLOCK), lds_bytes, ctx->stream, P);
             HIP_TRY(ctx, hipGetLastError());
             segments += live;
             launches++;
@@ -328,7 +473,7 @@ int launch_wavefront(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sam
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 
     hipFuncAttributes attr{};
-    HIP_TRY(ctx, hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_wf_bounce<FAST, SHADE_LDS>)));
+    HIP_TRY(ctx, hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_wf_bounce<FAST, KIND>)));
     ctx->last = pt_counters{};
     ctx->last.samples = (uint64_t)n_pixels * spp;
     ctx->last.vgprs = (uint32_t)attr.numRegs;
@@ -344,17 +489,14 @@ int render_dispatch(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_samp
     if ((uint64_t)first_sample + spp > 0xFFFFFFFFull)
         return fail(ctx, PT_E_LIMIT, "sample numbers must fit in 32 bits");
     if (mode & ~(PT_MODE_WAVEFRONT | PT_NUM_FAST)) return fail(ctx, PT_E_INVALID, "unknown mode bits 0x%x", mode);
-    const bool fast = (mode & PT_NUM_FAST) != 0, lds = ctx->n_surfaces <= MAX_LDS_SURFACES;
-    if (mode & PT_MODE_WAVEFRONT) {
-        if (fast) return lds ? launch_wavefront<true, true>(ctx, accum, spp, first_sample, seed)
-                             : launch_wavefront<true, false>(ctx, accum, spp, first_sample, seed);
-        return lds ? launch_wavefront<false, true>(ctx, accum, spp, first_sample, seed)
-                   : launch_wavefront<false, false>(ctx, accum, spp, first_sample, seed);
-    }
-    if (fast) return lds ? launch_render<true, true>(ctx, accum, spp, first_sample, seed)
-                         : launch_render<true, false>(ctx, accum, spp, first_sample, seed);
-    return lds ? launch_render<false, true>(ctx, accum, spp, first_sample, seed)
-               : launch_render<false, false>(ctx, accum, spp, first_sample, seed);
+    const bool fast = (mode & PT_NUM_FAST) != 0;
+    if (mode & PT_MODE_WAVEFRONT)
+        return with_variant(fast, scene_kind(ctx), [&]<bool FAST, int KIND>() {
+            return launch_wavefront<FAST, KIND>(ctx, accum, spp, first_sample, seed);
+        });
+    return with_variant(fast, scene_kind(ctx), [&]<bool FAST, int KIND>() {
+        return launch_render<FAST, KIND>(ctx, accum, spp, first_sample, seed);
+    });
 }
 
 }  // namespace
@@ -401,6 +543,9 @@ void pt_destroy(pt_ctx *ctx)
     for (hipEvent_t ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
     if (ctx->d_geom) (void)hipFree(ctx->d_geom);
     if (ctx->d_shade) (void)hipFree(ctx->d_shade);
+    if (ctx->d_loose) (void)hipFree(ctx->d_loose);
+    if (ctx->d_bvh_nodes) (void)hipFree(ctx->d_bvh_nodes);
+    if (ctx->d_bvh_leaves) (void)hipFree(ctx->d_bvh_leaves);
     if (ctx->d_accum) (void)hipFree(ctx->d_accum);
     if (ctx->d_slabs) (void)hipFree(ctx->d_slabs);
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
@@ -483,8 +628,23 @@ int pt_set_scene(pt_ctx *ctx, const pt_surface *surfaces, int32_t n_surfaces,
     ctx->n_tri = n_tri;
     ctx->n_sph = n_sph;
     memcpy(ctx->bg, bg, sizeof ctx->bg);
+    ctx->host_surfaces.assign(surfaces, surfaces + n_surfaces);
+    if ((rc = build_hierarchy(ctx, ctx->host_surfaces.data(), n_surfaces))) return rc;
     ctx->have_scene = true;
     return PT_OK;
+}
+
+int pt_set_accel(pt_ctx *ctx, int accel)
+{
+    if (!ctx) return fail(nullptr, PT_E_INVALID, "null context");
+    if (accel != PT_ACCEL_AUTO && accel != PT_ACCEL_NONE && accel != PT_ACCEL_BVH)
+        return fail(ctx, PT_E_INVALID, "unknown acceleration mode %d", accel);
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    ctx->accel = accel;
+    if (!ctx->have_scene) return PT_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return build_hierarchy(ctx, ctx->host_surfaces.data(), ctx->n_surfaces);
 }
 
 int pt_set_camera(pt_ctx *ctx, const pt_camera *cam)
@@ -598,7 +758,7 @@ int pt_tonemap_rgb8(pt_ctx *ctx, uint8_t *out_host)
     return PT_OK;
 }
 
-int pt_primary_hits(pt_ctx *ctx, int32_t *surf_idx, float *distance)
+int pt_primary_hits(pt_ctx *ctx, int32_t *surf_idx, float *distance, int numeric)
 {
     int rc = check_ready(ctx, true);
     if (rc) return rc;
@@ -608,8 +768,11 @@ int pt_primary_hits(pt_ctx *ctx, int32_t *surf_idx, float *distance)
     Scratch<float> d_dist;
     if ((rc = dev_alloc(ctx, &d_idx.p, (size_t)n))) return rc;
     if ((rc = dev_alloc(ctx, &d_dist.p, (size_t)n))) return rc;
-    hipLaunchKernelGGL(k_primary_hits<false>, dim3(blocks_for(n)), dim3(BLOCK), 0, ctx->stream,
-                       ctx->cam, ctx->d_geom, ctx->n_surfaces, d_idx.p, d_dist.p);
+    rc = with_variant((numeric & PT_NUM_FAST) != 0, scene_kind(ctx), [&]<bool FAST, int KIND>() {
+        hipLaunchKernelGGL((k_primary_hits<FAST, KIND>), dim3(blocks_for(n)), dim3(BLOCK), 0, ctx->stream,
+                           ctx->cam, scene_view(ctx), d_idx.p, d_dist.p);
+        return PT_OK;
+    });
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(surf_idx, d_idx.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(distance, d_dist.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -618,7 +781,7 @@ int pt_primary_hits(pt_ctx *ctx, int32_t *surf_idx, float *distance)
 }
 
 int pt_intersect_rays(pt_ctx *ctx, const float *origin, const float *dir, int64_t n,
-                      int32_t *surf_idx, float *distance, float *point)
+                      int32_t *surf_idx, float *distance, float *point, int numeric)
 {
     int rc = check_ready(ctx, false);
     if (rc) return rc;
@@ -632,8 +795,11 @@ int pt_intersect_rays(pt_ctx *ctx, const float *origin, const float *dir, int64_
     if ((rc = dev_alloc(ctx, &d_idx.p, (size_t)n))) return rc;
     if ((rc = dev_alloc(ctx, &d_dist.p, (size_t)n))) return rc;
     if ((rc = dev_alloc(ctx, &d_pt.p, (size_t)n * 3))) return rc;
-    hipLaunchKernelGGL(k_intersect_rays<false>, dim3(blocks_for(n)), dim3(BLOCK), 0, ctx->stream,
-                       ctx->d_geom, ctx->n_surfaces, d_o.p, d_d.p, (long long)n, d_idx.p, d_dist.p, d_pt.p);
+    rc = with_variant((numeric & PT_NUM_FAST) != 0, scene_kind(ctx), [&]<bool FAST, int KIND>() {
+        hipLaunchKernelGGL((k_intersect_rays<FAST, KIND>), dim3(blocks_for(n)), dim3(BLOCK), 0, ctx->stream,
+                           scene_view(ctx), d_o.p, d_d.p, (long long)n, d_idx.p, d_dist.p, d_pt.p);
+        return PT_OK;
+    });
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(surf_idx, d_idx.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(distance, d_dist.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));

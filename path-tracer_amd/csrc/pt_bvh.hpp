@@ -1,0 +1,262 @@
+// Bounding-volume hierarchy over a scene's small triangles, built on the GPU
+// (Morton codes, radix sort, Karras' parallel hierarchy, bottom-up refit) and
+// traversed per lane with a stack in LDS.  The reference has no acceleration
+// structure (an "octree" is a to-do note, src/main.cpp:75); this one returns
+// exactly what the reference's linear scan returns: the surface of smallest
+// Intersection::distance, and among equal distances the one earliest in scene
+// order (src/main.cpp:58-66).  Included by pt_kernels.hpp.
+#pragma once
+
+#include "pt_device.hpp"
+
+namespace ptd {
+
+// A node holds the boxes of its two children:
+//   q[0] = (left min xyz, left ref)   q[1] = (left max xyz, right ref)
+//   q[2] = (right min xyz, -)         q[3] = (right max xyz, -)
+// A child ref >= 0 is an internal node, < 0 is leaf ~ref (position in Morton order).
+constexpr int BVH_NODE_QUADS = 4;
+// A leaf is one triangle: its geometry record (GEOM_STRIDE floats) with the
+// surface's index in scene order in element 3 (where a geometry record keeps the kind).
+constexpr int BVH_STACK = 64;        // deepest possible tree: 30 Morton bits + 32 index bits
+
+struct BvhView {
+    const float4 *nodes;     // n_leaves - 1 internal nodes, root = 0
+    const float *leaves;     // n_leaves * GEOM_STRIDE
+    int n_leaves;            // 0: the scene has no hierarchy
+};
+
+// ---------------------------------------------------------------- build
+
+PT_DEV uint32_t spread10(uint32_t v)     // 10 bits -> every third bit
+{
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+// Per hierarchy triangle j (scene index tri_idx[j]): padded box, 64-bit sort key
+// = 30-bit Morton code of the centroid, then j (keys are unique).
+// The pad covers the reference's tolerance outside the triangle (u, v >= -1e-5
+// of an edge length) and the rounding of hit points.
+__global__ void __launch_bounds__(256)
+k_bvh_prepare(const float *geom, const int *tri_idx, int n, float3 cmin, float3 cinv,
+              unsigned long long *keys, float4 *box_min, float4 *box_max)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const float *g = geom + (size_t)tri_idx[j] * GEOM_STRIDE;
+    const V3 v0 = v3(g[0], g[1], g[2]);
+    const V3 v1 = v0 + v3(g[4], g[5], g[6]), v2 = v0 + v3(g[8], g[9], g[10]);
+    V3 lo = v3(fminf(v0.x, fminf(v1.x, v2.x)), fminf(v0.y, fminf(v1.y, v2.y)), fminf(v0.z, fminf(v1.z, v2.z)));
+    V3 hi = v3(fmaxf(v0.x, fmaxf(v1.x, v2.x)), fmaxf(v0.y, fmaxf(v1.y, v2.y)), fmaxf(v0.z, fmaxf(v1.z, v2.z)));
+    const float size = (hi.x - lo.x) + (hi.y - lo.y) + (hi.z - lo.z);
+    const float reach = fmaxf(fmaxf(fabsf(lo.x), fabsf(hi.x)), fmaxf(fmaxf(fabsf(lo.y), fabsf(hi.y)), fmaxf(fabsf(lo.z), fabsf(hi.z))));
+    const float pad = 1e-3f * size + 1e-5f * (1.0f + reach);
+    box_min[j] = make_float4(lo.x - pad, lo.y - pad, lo.z - pad, 0.0f);
+    box_max[j] = make_float4(hi.x + pad, hi.y + pad, hi.z + pad, 0.0f);
+    const float cx = ((lo.x + hi.x) * 0.5f - cmin.x) * cinv.x;
+    const float cy = ((lo.y + hi.y) * 0.5f - cmin.y) * cinv.y;
+    const float cz = ((lo.z + hi.z) * 0.5f - cmin.z) * cinv.z;
+    const uint32_t qx = (uint32_t)fminf(fmaxf(cx * 1024.0f, 0.0f), 1023.0f);
+    const uint32_t qy = (uint32_t)fminf(fmaxf(cy * 1024.0f, 0.0f), 1023.0f);
+    const uint32_t qz = (uint32_t)fminf(fmaxf(cz * 1024.0f, 0.0f), 1023.0f);
+    const uint32_t code = (spread10(qx) << 2) | (spread10(qy) << 1) | spread10(qz);
+    keys[j] = ((unsigned long long)code << 32) | (uint32_t)j;
+}
+
+// Length of the common prefix of sorted keys i and j; -1 outside the array.
+PT_DEV int bvh_delta(const unsigned long long *keys, int n, int i, int j)
+{
+    if (j < 0 || j >= n) return -1;
+    return __clzll((long long)(keys[i] ^ keys[j]));
+}
+
+// One thread per internal node: its key range, its split, its children
+// (Karras, "Maximizing parallelism in the construction of BVHs...", 2012).
+// child >= 0: internal node; child < 0: leaf ~child.
+__global__ void __launch_bounds__(256)
+k_bvh_hierarchy(const unsigned long long *keys, int n, int2 *children, int *parent_of_node, int *parent_of_leaf)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = bvh_delta(keys, n, i, i + 1) - bvh_delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
+    const int dmin = bvh_delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (bvh_delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (bvh_delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = bvh_delta(keys, n, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) / 2;
+        if (bvh_delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    int2 c;
+    if (lo == gamma) { c.x = ~gamma; parent_of_leaf[gamma] = i; }
+    else { c.x = gamma; parent_of_node[gamma] = i; }
+    if (hi == gamma + 1) { c.y = ~(gamma + 1); parent_of_leaf[gamma + 1] = i; }
+    else { c.y = gamma + 1; parent_of_node[gamma + 1] = i; }
+    children[i] = c;
+    if (i == 0) parent_of_node[0] = -1;
+}
+
+// One thread per leaf climbs towards the root.  At every node the first of
+// the two arriving children leaves its box in the node and stops; the second
+// reads it, forms the union and goes on.  arrivals[] is zeroed before the
+// launch.  Every hand-off is: write box, agent-scope fence, counter add /
+// counter add, agent-scope fence, read box.
+__global__ void __launch_bounds__(256)
+k_bvh_refit(const unsigned long long *keys, int n, const int2 *children, const int *parent_of_node,
+            const int *parent_of_leaf, const float4 *box_min, const float4 *box_max,
+            unsigned int *arrivals, float4 *nodes)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const int j = (int)(uint32_t)keys[k];
+    float4 lo = box_min[j], hi = box_max[j];
+    int child = ~k;
+    int p = parent_of_leaf[k];
+    while (p >= 0) {
+        const int2 c = children[p];
+        const bool is_left = c.x == child;
+        float4 *q = nodes + (size_t)p * BVH_NODE_QUADS;
+        // the refs travel in the w components of the first two quads
+        if (is_left) {
+            q[0] = make_float4(lo.x, lo.y, lo.z, __int_as_float(c.x));
+            q[1] = make_float4(hi.x, hi.y, hi.z, __int_as_float(c.y));
+        } else {
+            q[2] = make_float4(lo.x, lo.y, lo.z, 0.0f);
+            q[3] = make_float4(hi.x, hi.y, hi.z, 0.0f);
+        }
+        __threadfence();
+        if (atomicAdd(arrivals + p, 1u) == 0u) return;      // the sibling will finish this node
+        __threadfence();
+        const volatile float4 *vq = q;
+        const int o = is_left ? 2 : 0;                      // the sibling's box
+        const float sx0 = vq[o].x, sy0 = vq[o].y, sz0 = vq[o].z;
+        const float sx1 = vq[o + 1].x, sy1 = vq[o + 1].y, sz1 = vq[o + 1].z;
+        lo = make_float4(fminf(lo.x, sx0), fminf(lo.y, sy0), fminf(lo.z, sz0), 0.0f);
+        hi = make_float4(fmaxf(hi.x, sx1), fmaxf(hi.y, sy1), fmaxf(hi.z, sz1), 0.0f);
+        child = p;
+        p = parent_of_node[p];
+    }
+}
+
+// Leaf records in Morton order: the triangle's geometry record with the scene
+// index in place of the kind.
+__global__ void __launch_bounds__(256)
+k_bvh_leaves(const unsigned long long *keys, int n, const float *geom, const int *tri_idx, float *leaves)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const int i = tri_idx[(int)(uint32_t)keys[k]];
+    const float4 *src = reinterpret_cast<const float4 *>(geom + (size_t)i * GEOM_STRIDE);
+    float4 *dst = reinterpret_cast<float4 *>(leaves + (size_t)k * GEOM_STRIDE);
+    float4 a = src[0];
+    a.w = __int_as_float(i);
+    dst[0] = a; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+}
+
+// ---------------------------------------------------------------- traversal
+
+// Entry parameter of the ray into a box, or a negative value if it misses or
+// the box lies wholly beyond t_far.  inv = 1/d per component.
+PT_DEV float box_entry(float4 bmin, float4 bmax, V3 o, V3 inv, float t_far)
+{
+    const float x1 = (bmin.x - o.x) * inv.x, x2 = (bmax.x - o.x) * inv.x;
+    const float y1 = (bmin.y - o.y) * inv.y, y2 = (bmax.y - o.y) * inv.y;
+    const float z1 = (bmin.z - o.z) * inv.z, z2 = (bmax.z - o.z) * inv.z;
+    // fminf/fmaxf drop a NaN operand (0 * inf when the ray lies in a box face)
+    const float t_in = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fmaxf(fminf(z1, z2), 0.0f));
+    const float t_out = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fminf(fmaxf(z1, z2), t_far));
+    return t_in <= t_out ? t_in : -1.0f;
+}
+
+// Continues a closest-hit search through the hierarchy.  On entry `best` is
+// the exact closest hit among the surfaces outside the hierarchy (idx < 0:
+// none, dist = +inf); on exit it is the closest hit overall, with the
+// reference's t and distance.  stack: BVH_STACK ints per lane, lane-strided
+// (stack[level * stride]).
+template <bool FAST>
+PT_DEV void closest_in_bvh(const BvhView &bvh, V3 o, V3 d, Hit &best, int *stack, int stride)
+{
+    using N = Num<FAST>;
+    const V3 nd = -d;
+    const V3 inv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    const float len_d = __builtin_amdgcn_sqrtf(N::dot(d, d));
+    const float inv_len = __builtin_amdgcn_rcpf(len_d);
+    int sp = 0;
+    int node = bvh.n_leaves > 1 ? 0 : ~0;
+    for (;;) {
+        if (node >= 0) {
+            const float4 *q = bvh.nodes + (size_t)node * BVH_NODE_QUADS;
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            // nothing beyond the best distance can win; the margin covers the rounding of t * |d|
+            const float t_far = best.dist * inv_len * (1.0f + 1e-5f);
+            const float tl = box_entry(q0, q1, o, inv, t_far);
+            const float tr = box_entry(q2, q3, o, inv, t_far);
+            const int left = __float_as_int(q0.w), right = __float_as_int(q1.w);
+            if (tl >= 0.0f && tr >= 0.0f) {                 // both: nearer first
+                const bool left_first = tl <= tr;
+                stack[sp * stride] = left_first ? right : left;
+                sp++;
+                node = left_first ? left : right;
+                continue;
+            }
+            if (tl >= 0.0f) { node = left; continue; }
+            if (tr >= 0.0f) { node = right; continue; }
+        } else {
+            const float *g = bvh.leaves + (size_t)(~node) * GEOM_STRIDE;
+            const float4 g0 = *reinterpret_cast<const float4 *>(g);
+            const float4 g1 = *reinterpret_cast<const float4 *>(g + 4);
+            const float4 g2 = *reinterpret_cast<const float4 *>(g + 8);
+            const int idx = __float_as_int(g0.w);
+            const TriDets q = triangle_dets_v<FAST>(v3(g0.x, g0.y, g0.z), v3(g1.x, g1.y, g1.z), g1.w,
+                                                    v3(g2.x, g2.y, g2.z), o, nd);
+            const float rinv = __builtin_amdgcn_rcpf(q.det_a);
+            const float u = q.du * rinv, v = q.dv * rinv, t = q.dt * rinv;
+            const float s = u + v;
+            const bool det_bad = q.det_a >= -EPS_F && q.det_a <= EPS_F;
+            if constexpr (FAST) {
+                const bool acc = !(det_bad | (u < -EPS_F) | (u >= 1.0f) | (v < -EPS_F) | (s >= 1.0f) | (t <= EPS_F));
+                const float dist = t * len_d;
+                if (acc & (dist < best.dist)) { best.idx = idx; best.t = t; best.dist = dist; }
+            } else {
+                const bool rej = det_bad | (u < BAND_LO_REJ) | (u > BAND_ONE_REJ) | (v < BAND_LO_REJ) |
+                                 (s > BAND_ONE_REJ) | (t < BAND_T_REJ);
+                // a sure hit farther than the best, by more than the error of the estimate, cannot win
+                const bool farther = t * len_d * (1.0f - TRI_DIST_ERR) > best.dist;
+                if (!(rej | farther)) {
+                    // exact evaluation, as Triangle::intersects does it (src/surface.hpp:53-70)
+                    bool ok = !det_bad;
+                    const float ue = q.du / q.det_a;
+                    ok = ok & !(ue < -EPS_F || ue >= 1.0f);
+                    const float ve = q.dv / q.det_a;
+                    ok = ok & !(ve < -EPS_F || ue + ve >= 1.0f);
+                    const float te = q.dt / q.det_a;
+                    ok = ok & !(te <= EPS_F);
+                    const V3 td = d * te;
+                    const float dist = __builtin_sqrtf(N::dot(td, td));
+                    // smallest distance wins; equal distances: the earlier surface in scene order
+                    if (ok & ((dist < best.dist) | ((dist == best.dist) & (idx < best.idx) & (best.idx >= 0)))) {
+                        best.idx = idx;
+                        best.t = te;
+                        best.dist = dist;
+                    }
+                }
+            }
+        }
+        if (sp == 0) break;
+        sp--;
+        node = stack[sp * stride];
+    }
+}
+
+}  // namespace ptd

@@ -219,13 +219,9 @@ constexpr float EPS_F = 1e-5f;
 struct TriDets { float det_a, du, dv, dt; };
 
 template <bool FAST>
-PT_DEV TriDets triangle_dets(cfloat_p g, V3 o, V3 nd)
+PT_DEV TriDets triangle_dets_v(V3 v0, V3 e1, float m_e, V3 e2, V3 o, V3 nd)
 {
     using N = Num<FAST>;
-    const V3 v0 = v3(g[0], g[1], g[2]);
-    const V3 e1 = v3(g[4], g[5], g[6]);
-    const V3 e2 = v3(g[8], g[9], g[10]);
-    const float m_e = g[7];                              // e1.y*e2.z - e2.y*e1.z
     const V3 b = o - v0;                                 // :56
     const float m_de2 = N::msub(nd.y, e2.z, e2.y, nd.z);
     const float m_de1 = N::msub(nd.y, e1.z, e1.y, nd.z);
@@ -246,6 +242,13 @@ PT_DEV TriDets triangle_dets(cfloat_p g, V3 o, V3 nd)
         r.dt = b.x * m_e - e1.x * m_be2 + e2.x * m_be1;
     }
     return r;
+}
+
+// The same from a geometry record read with a wave-uniform index.
+template <bool FAST>
+PT_DEV TriDets triangle_dets(cfloat_p g, V3 o, V3 nd)
+{
+    return triangle_dets_v<FAST>(v3(g[0], g[1], g[2]), v3(g[4], g[5], g[6]), g[7], v3(g[8], g[9], g[10]), o, nd);
 }
 
 // Triangle::intersects, src/surface.hpp:47-73, evaluated directly: IEEE
@@ -309,14 +312,16 @@ PT_DEV bool sphere_direct(cfloat_p g, V3 o, V3 d, float &t_out, float &dist_out)
 // closest_intersection, src/main.cpp:56-67, evaluated directly: scene order,
 // a later surface replaces the current one only when strictly closer.
 template <bool FAST>
-PT_DEV Hit closest_direct(cfloat_p geom, int n_surfaces, V3 o, V3 d)
+PT_DEV Hit closest_direct(cfloat_p geom, int n_surfaces, V3 o, V3 d, const int *index_map = nullptr)
 {
     Hit best;
     best.idx = -1;
     best.t = 0.0f;
     best.dist = 0.0f;
     const V3 nd = -d;
-    for (int i = 0; i < n_surfaces; i++) {
+    for (int j = 0; j < n_surfaces; j++) {
+        // index_map (ascending scene indices) restricts the scan to a subset of the scene
+        const int i = index_map ? index_map[j] : j;
         cfloat_p g = geom + (size_t)i * GEOM_STRIDE;
         float t, dist;
         bool ok;

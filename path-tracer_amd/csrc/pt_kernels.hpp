@@ -2,6 +2,7 @@
 #pragma once
 
 #include "pt_device.hpp"
+#include "pt_bvh.hpp"
 
 namespace ptd {
 
@@ -11,12 +12,43 @@ constexpr uint32_t NO_ITEM = 0xFFFFFFFFu;
 constexpr int MAX_DEPTH = 1024;      // PT_MAX_DEPTH
 constexpr int MAX_LDS_SURFACES = 64 * 1024 / (12 * 4);   // shading records kept in LDS (64 KiB)
 
+// How a kernel sees the scene.  Without a hierarchy every surface is scanned
+// in scene order.  With one (scenes of many triangles) the spheres and the
+// large triangles are scanned, by their scene indices in `loose`, and the
+// small triangles are searched through the hierarchy.
+struct SceneView {
+    const float *geom;        // every surface's geometry record, scene order, read through the scalar cache
+    const float *shade;       // every surface's shading record
+    int n_scan;               // surfaces scanned linearly
+    int n_surfaces;           // surfaces in the scene
+    const int *loose;         // with a hierarchy: the n_scan scene indices to scan, ascending
+    BvhView bvh;
+    float bg[3];
+};
+
+// Scene kinds a kernel is compiled for.
+constexpr int SCENE_LDS = 0;      // shading records staged in LDS, linear scan
+constexpr int SCENE_GLOBAL = 1;   // shading records read from global memory, linear scan
+constexpr int SCENE_BVH = 2;      // shading records from global memory, scan + hierarchy
+
+template <bool FAST, bool NEED_DIST, int KIND>
+PT_DEV Hit closest_hit(const SceneView &sc, V3 o, V3 d, unsigned long long *redo_count = nullptr)
+{
+    if constexpr (KIND != SCENE_BVH) {
+        return closest_intersection<FAST, NEED_DIST>(as_constant(sc.geom), sc.n_scan, o, d, redo_count);
+    } else {
+        Hit h = closest_direct<FAST>(as_constant(sc.geom), sc.n_scan, o, d, sc.loose);
+        if (h.idx < 0) h.dist = __builtin_inff();
+        int stack[BVH_STACK];
+        closest_in_bvh<FAST>(sc.bvh, o, d, h, stack, 1);
+        if (h.idx < 0) h.dist = 0.0f;
+        return h;
+    }
+}
+
 struct RenderParams {
     Camera cam;
-    const float *geom;        // n_surfaces * GEOM_STRIDE, read through the scalar cache
-    const float *shade;       // n_surfaces * SHADE_STRIDE, staged in LDS
-    int n_surfaces;
-    float bg[3];
+    SceneView scene;
     uint32_t seed_mix;
     uint32_t first_sample;
     uint32_t spp;
@@ -31,30 +63,30 @@ struct RenderParams {
 // ---------------------------------------------------------------- parity kernels
 
 // One thread per pixel: the ray through the pixel's integer corner, closest hit.
-template <bool FAST>
+template <bool FAST, int KIND>
 __global__ void __launch_bounds__(BLOCK)
-k_primary_hits(Camera cam, const float *geom_g, int n_surfaces, int32_t *idx, float *dist)
+k_primary_hits(Camera cam, SceneView scene, int32_t *idx, float *dist)
 {
     const int p = blockIdx.x * BLOCK + threadIdx.x;
     if (p >= cam.width * cam.height) return;
     const int x = p % cam.width, y = p / cam.width;
     const V3 o = v3(cam.pos[0], cam.pos[1], cam.pos[2]);
     const V3 d = ray_direction_by_pixel<FAST>(cam, (float)x, (float)y);
-    const Hit h = closest_intersection<FAST, true>(as_constant(geom_g), n_surfaces, o, d);
+    const Hit h = closest_hit<FAST, true, KIND>(scene, o, d);
     idx[p] = h.idx;
     dist[p] = h.idx < 0 ? 0.0f : h.dist;
 }
 
-template <bool FAST>
+template <bool FAST, int KIND>
 __global__ void __launch_bounds__(BLOCK)
-k_intersect_rays(const float *geom_g, int n_surfaces, const float *org, const float *dir,
+k_intersect_rays(SceneView scene, const float *org, const float *dir,
                  long long n, int32_t *idx, float *dist, float *point)
 {
     const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const V3 o = v3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
     const V3 d = v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
-    const Hit h = closest_intersection<FAST, true>(as_constant(geom_g), n_surfaces, o, d);
+    const Hit h = closest_hit<FAST, true, KIND>(scene, o, d);
     idx[i] = h.idx;
     dist[i] = h.idx < 0 ? 0.0f : h.dist;
     V3 pt = v3(0, 0, 0);
@@ -149,13 +181,13 @@ PT_DEV void path_begin(PathState &ps, const Camera &cam, uint32_t pixel_key, uin
 // (each within 1 ulp) in both modes: the reference evaluates them through libm
 // in double, which no fp32 path matches bit for bit, and they are checked to
 // 1e-5 instead.
-template <bool FAST>
-PT_DEV bool path_segment(PathState &ps, cfloat_p geom, int n_surfaces, const float *shade,
-                         const float (&bg)[3], unsigned long long *redo_count)
+template <bool FAST, int KIND>
+PT_DEV bool path_segment(PathState &ps, const SceneView &sc, const float *shade, unsigned long long *redo_count)
 {
     using N = Num<FAST>;
     using S = Num<true>;
-    const Hit h = closest_intersection<FAST, false>(geom, n_surfaces, ps.o, ps.d, redo_count);
+    const float (&bg)[3] = sc.bg;
+    const Hit h = closest_hit<FAST, false, KIND>(sc, ps.o, ps.d, redo_count);
     if (h.idx < 0) {                                // main.cpp:105-108
         ps.col = v3(S::mad(bg[0], ps.thr.x, ps.col.x), S::mad(bg[1], ps.thr.y, ps.col.y),
                     S::mad(bg[2], ps.thr.z, ps.col.z));
@@ -203,23 +235,22 @@ PT_DEV bool path_segment(PathState &ps, cfloat_p geom, int n_surfaces, const flo
 // lanes from a wave-uniform pool.  A lane leaves the loop when the queue is
 // empty: every wave reaches that state, so the grid always drains.
 //
-// SHADE_LDS: the shading records fit in LDS and are staged there once per
-// workgroup; otherwise (scenes above MAX_LDS_SURFACES) lanes read them from
-// global memory.
-template <bool FAST, bool SHADE_LDS>
+// KIND: SCENE_LDS when the shading records fit in LDS (staged there once per
+// workgroup), SCENE_GLOBAL when lanes read them from global memory (scenes
+// above MAX_LDS_SURFACES), SCENE_BVH when the scene has a hierarchy.
+template <bool FAST, int KIND>
 __global__ void __launch_bounds__(BLOCK)
 k_render_mega(RenderParams P)
 {
     extern __shared__ __align__(16) float lds_shade[];
-    const float *shade = P.shade;
-    if constexpr (SHADE_LDS) {
-        for (int i = threadIdx.x; i < P.n_surfaces * SHADE_STRIDE; i += BLOCK)
-            lds_shade[i] = P.shade[i];
+    const float *shade = P.scene.shade;
+    if constexpr (KIND == SCENE_LDS) {
+        for (int i = threadIdx.x; i < P.scene.n_surfaces * SHADE_STRIDE; i += BLOCK)
+            lds_shade[i] = P.scene.shade[i];
         __syncthreads();
         shade = lds_shade;
     }
 
-    const cfloat_p geom = as_constant(P.geom);
     const uint32_t lane = __lane_id();
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
@@ -285,7 +316,7 @@ k_render_mega(RenderParams P)
             path_begin(ps, P.cam, pixel_key, s, px, py);
             need_path = false;
         }
-        const bool ended = path_segment<FAST>(ps, geom, P.n_surfaces, shade, P.bg, P.stats + 1);
+        const bool ended = path_segment<FAST, KIND>(ps, P.scene, shade, P.stats + 1);
         n_seg++;
         if (ended) {
             sum = sum + ps.col;                 // buffer[u][v] += color, main.cpp:139
@@ -329,9 +360,7 @@ constexpr uint32_t WF_COUNT_STRIDE = 32;     // uint32 words between two counter
 
 struct WfParams {
     Camera cam;
-    const float *geom, *shade;
-    int n_surfaces;
-    float bg[3];
+    SceneView scene;
     uint32_t seed_mix;
     uint32_t first_sample;     // global number of the batch's first sample
     uint32_t n_pixels;
@@ -367,15 +396,15 @@ k_wf_generate(WfParams P)
     wf_store(P.in, shard * P.shard_cap + local * BLOCK + threadIdx.x, ps, i);
 }
 
-template <bool FAST, bool SHADE_LDS>
+template <bool FAST, int KIND>
 __global__ void __launch_bounds__(BLOCK)
 k_wf_bounce(WfParams P)
 {
     extern __shared__ __align__(16) float lds_shade[];
-    const float *shade = P.shade;
-    if constexpr (SHADE_LDS) {
-        for (int i = threadIdx.x; i < P.n_surfaces * SHADE_STRIDE; i += BLOCK)
-            lds_shade[i] = P.shade[i];
+    const float *shade = P.scene.shade;
+    if constexpr (KIND == SCENE_LDS) {
+        for (int i = threadIdx.x; i < P.scene.n_surfaces * SHADE_STRIDE; i += BLOCK)
+            lds_shade[i] = P.scene.shade[i];
         __syncthreads();
         shade = lds_shade;
     }
@@ -398,7 +427,7 @@ k_wf_bounce(WfParams P)
         ps.rng.ctr = d.y;
         ps.depth = (int)d.z;
         slot = d.w;
-        const bool ended = path_segment<FAST>(ps, as_constant(P.geom), P.n_surfaces, shade, P.bg, P.stats + 1);
+        const bool ended = path_segment<FAST, KIND>(ps, P.scene, shade, P.stats + 1);
         if (ended) {
             float *r = P.result + 3ull * slot;
             r[0] = ps.col.x; r[1] = ps.col.y; r[2] = ps.col.z;

@@ -225,7 +225,7 @@ inline bool gpu_intersect(const pt_surface &surface, vec3 start, vec3 dir, vec3 
     const float o[3] = {start.x, start.y, start.z}, d[3] = {dir.x, dir.y, dir.z};
     int32_t idx = -1;
     float pt3[3] = {0, 0, 0};
-    rc = pt_intersect_rays(probe.context(), o, d, 1, &idx, &distance, pt3);
+    rc = pt_intersect_rays(probe.context(), o, d, 1, &idx, &distance, pt3, PT_NUM_EXACT);
     if (rc != PT_OK) throw Error(rc, pt_last_error(probe.context()));
     point = vec3(pt3[0], pt3[1], pt3[2]);
     return idx == 0;

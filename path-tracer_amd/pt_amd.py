@@ -25,6 +25,7 @@ TRIANGLE, SPHERE = 0, 1
 MODE_MEGAKERNEL, MODE_WAVEFRONT = 0x0, 0x1
 NUM_EXACT, NUM_FAST = 0x0, 0x10
 MAX_DEPTH = 1024
+ACCEL_AUTO, ACCEL_NONE, ACCEL_BVH = 0, 1, 2
 
 SCENE_NAMES = ("dof_demo", "test", "orange_plane", "red_corner", "sunrise",
                "cornell_2", "cornell")
@@ -32,7 +33,7 @@ SCENE_NAMES = ("dof_demo", "test", "orange_plane", "red_corner", "sunrise",
 # Every symbol include/pt_amd.h declares.
 ABI_SYMBOLS = (
     "pt_global_error", "pt_create", "pt_destroy", "pt_last_error", "pt_set_stream",
-    "pt_set_scene", "pt_set_camera", "pt_clear", "pt_render", "pt_render_into",
+    "pt_set_scene", "pt_set_accel", "pt_set_camera", "pt_clear", "pt_render", "pt_render_into",
     "pt_read_accum", "pt_write_accum", "pt_tonemap_rgb8", "pt_primary_hits", "pt_intersect_rays",
     "pt_camera_rays", "pt_eval_bsdf", "pt_eval_brdf", "pt_rng_uniform", "pt_get_counters",
 )
@@ -182,6 +183,9 @@ class Context:
         self._check(self._lib.pt_set_scene(self._h, _p(surfaces), C.c_int32(len(surfaces)),
                                            _p(materials), C.c_int32(len(materials)), _p(bg)))
 
+    def set_accel(self, accel):
+        self._check(self._lib.pt_set_accel(self._h, C.c_int(accel)))
+
     def set_camera(self, camera):
         camera = np.ascontiguousarray(camera, dtype=CAMERA).reshape(1)
         self._check(self._lib.pt_set_camera(self._h, _p(camera)))
@@ -223,13 +227,13 @@ class Context:
         self._check(self._lib.pt_tonemap_rgb8(self._h, _p(out)))
         return out
 
-    def primary_hits(self):
+    def primary_hits(self, numeric=NUM_EXACT):
         idx = np.empty((self.height, self.width), dtype=np.int32)
         dist = np.empty((self.height, self.width), dtype=np.float32)
-        self._check(self._lib.pt_primary_hits(self._h, _p(idx), _p(dist)))
+        self._check(self._lib.pt_primary_hits(self._h, _p(idx), _p(dist), C.c_int(numeric)))
         return idx, dist
 
-    def intersect_rays(self, origin, direction):
+    def intersect_rays(self, origin, direction, numeric=NUM_EXACT):
         origin = np.ascontiguousarray(origin, dtype=np.float32)
         direction = np.ascontiguousarray(direction, dtype=np.float32)
         n = origin.shape[0] if origin.ndim == 2 else 0
@@ -237,7 +241,7 @@ class Context:
         dist = np.empty(n, dtype=np.float32)
         point = np.empty((n, 3), dtype=np.float32)
         self._check(self._lib.pt_intersect_rays(self._h, _p(origin), _p(direction), C.c_int64(n),
-                                                _p(idx), _p(dist), _p(point)))
+                                                _p(idx), _p(dist), _p(point), C.c_int(numeric)))
         return idx, dist, point
 
     def camera_rays(self, px, xi, numeric=NUM_EXACT):

@@ -428,3 +428,122 @@ def test_million_triangle_scene_primary_hits(ctx, pt, orc):
     oidx, odist = orc.primary_hits(as_oracle_scene(orc, sc))
     assert np.array_equal(idx, oidx) and np.array_equal(dist, odist)
     assert len(np.unique(idx)) > 20 and (idx < 999698).sum() > 20
+
+
+# ---------------------------------------------------------------- the C++ drop-in
+
+def test_cpp_headless_trace_rays_drop_in(pt, orc, tmp_path):
+    """pt_headless drives the C++ mirror: Scenes::cornell_2(), then trace_rays(scene, buffer)
+    once per pass, as the reference's main loop does; its image mean must match the oracle's
+    and its PPM must be the tone-mapped buffer."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "path-tracer_amd", "lib", "pt_headless")
+    out = str(tmp_path / "img.ppm")
+    res = subprocess.run([exe, "-scene", "cornell_2", "-width", "96", "-height", "64", "-passes", "12",
+                          "-out", out], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    fields = dict(kv.split("=") for kv in res.stdout.split())
+    assert fields["samples_per_pixel"] == "12" and fields["size"] == "96x64"
+    mean = np.float64(fields["mean_rgb"].split(","))
+    oacc, _ = orc.render(orc.builtin_scene("cornell_2", 96, 64), 12, first_sample=0, seed=1, threads=8)
+    assert np.allclose(mean, oacc.mean((0, 1)) / 12, rtol=2e-3)
+    assert "10" in res.stderr.split()                      # progress line every 10 passes
+    data = open(out, "rb").read()
+    assert data.startswith(b"P6\n96 64\n255\n") and len(data) == len(b"P6\n96 64\n255\n") + 96 * 64 * 3
+    img = np.frombuffer(data[-96 * 64 * 3:], np.uint8).reshape(64, 96, 3)
+    want = orc.tonemap(oacc, 12)
+    assert (np.abs(img.astype(int) - want.astype(int)) <= 2).mean() > 0.98
+    # batched form: sums stay on the device
+    res = subprocess.run([exe, "-scene", "orange_plane", "-width", "64", "-height", "40", "-passes", "2",
+                          "-batch", "8"], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    fields = dict(kv.split("=") for kv in res.stdout.split())
+    assert fields["samples_per_pixel"] == "16"
+    res = subprocess.run([exe, "-scene", "nope"], capture_output=True, text=True, timeout=60)
+    assert res.returncode == 2
+
+
+# ---------------------------------------------------------------- hierarchy (BVH) vs the linear scan
+
+def test_hierarchy_equals_linear_scan_small_scenes(ctx, pt, orc):
+    """Forcing the hierarchy on the built-in scenes (5-15 triangles) changes nothing:
+    bit-exact closest hits, ties included."""
+    rng = np.random.default_rng(21)
+    try:
+        for name in ("cornell", "cornell_2", "red_corner"):
+            sc = pt.builtin_scene(name, 64, 64)
+            osc = orc.builtin_scene(name, 64, 64)
+            ctx.set_accel(pt.ACCEL_BVH)
+            load(ctx, sc)
+            o, d = random_rays(rng, 100000)
+            i0, _, p0 = orc.intersect_rays(osc, o[:30000], d[:30000])
+            o[:30000][i0 >= 0] = p0[i0 >= 0]
+            got = ctx.intersect_rays(o, d)
+            want = orc.intersect_rays(osc, o, d)
+            for g, w in zip(got, want):
+                assert np.array_equal(g, w), name
+            idx, dist = ctx.primary_hits()
+            oidx, odist = orc.primary_hits(osc)
+            assert np.array_equal(idx, oidx) and np.array_equal(dist, odist)
+    finally:
+        ctx.set_accel(pt.ACCEL_AUTO)
+
+
+def test_hierarchy_ties_and_duplicates(ctx, pt, orc):
+    """Coincident triangles inside the hierarchy: the earliest in scene order wins."""
+    rng = np.random.default_rng(8)
+    n = 600
+    surf = np.zeros(n, dtype=pt.SURFACE)
+    surf["material"] = 0
+    base = rng.uniform(-2, 2, (n // 3, 3))
+    for rep in range(3):                               # every triangle appears three times
+        sl = slice(rep * (n // 3), (rep + 1) * (n // 3))
+        surf["a"][sl] = base
+        surf["b"][sl] = base + [0.5, 0, 0.1]
+        surf["c"][sl] = base + [0, 0.5, 0.1]
+    perm = rng.permutation(n)
+    surf = surf[perm]
+    mats = np.zeros(1, dtype=pt.MATERIAL)
+    osc = orc.Scene(surf.view(orc.SURFACE), mats.view(orc.MATERIAL), [0, 0, 0],
+                    orc.camera_init([0, 0, 0], 0, 0, 8, 0, 8, 8))
+    o, d = random_rays(rng, 50000, 3.0)
+    want = orc.intersect_rays(osc, o, d)
+    try:
+        for accel in (pt.ACCEL_BVH, pt.ACCEL_NONE):
+            ctx.set_accel(accel)
+            ctx.set_scene(surf, mats, [0, 0, 0])
+            got = ctx.intersect_rays(o, d)
+            for g, w in zip(got, want):
+                assert np.array_equal(g, w), accel
+    finally:
+        ctx.set_accel(pt.ACCEL_AUTO)
+    assert (want[0] >= 0).sum() > 5000
+
+
+def test_hierarchy_on_the_million_triangle_scene(ctx, pt):
+    """999,705 surfaces: hierarchy against the brute-force scan on the GPU, bit-exact, and a
+    render that finishes."""
+    sc = pt.builtin_scene("heightfield", 200, 120)
+    rng = np.random.default_rng(3)
+    o = np.stack([rng.uniform(-3, 3, 3000), rng.uniform(-1.5, 0.8, 3000), rng.uniform(-1, 8, 3000)], 1)
+    d = rng.normal(size=(3000, 3))
+    d[:, 1] = np.abs(d[:, 1])                          # mostly downwards, onto the field (y is down)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    try:
+        ctx.set_accel(pt.ACCEL_NONE)
+        load(ctx, sc)
+        want = ctx.intersect_rays(o, d)
+        ctx.set_accel(pt.ACCEL_AUTO)
+        load(ctx, sc)
+        got = ctx.intersect_rays(o, d)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
+        assert (want[0] >= 0).sum() > 1500 and len(np.unique(want[0])) > 1000
+        ctx.render(4, 0, 1, 0)
+        acc, total = ctx.read_accum()
+        c = ctx.counters()
+        assert total == 4 and np.isfinite(acc).all() and acc.sum() > 0
+        assert c.segments > 2 * c.samples
+    finally:
+        ctx.set_accel(pt.ACCEL_AUTO)
