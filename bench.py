@@ -168,6 +168,19 @@ def main():
             "vgprs": int(c.vgprs),
             "grid_blocks": int(c.grid_blocks),
         }
+        if world == 1 and args.layout == "megakernel":
+            # the other numeric policy on the same workload, for the record (not the headline)
+            other = "fast" if args.numeric == "exact" else "exact"
+            omode = pt_amd.MODE_MEGAKERNEL | (pt_amd.NUM_FAST if other == "fast" else pt_amd.NUM_EXACT)
+            ms = []
+            for i in range(2):
+                ctx.render_into(accum.data_ptr(), args.spp, (args.warmup + args.steps + i) * args.spp,
+                                args.seed, omode)
+                oc = ctx.counters()
+                ms.append(oc.kernel_ms)
+            out["other_numeric"] = {"numeric": other, "kernel_ms": min(ms),
+                                    "value": width * height * args.spp / (min(ms) * 1e-3) / 1e6,
+                                    "roofline_frac": oc.flops / (min(ms) * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS}
         if world == 1 and args.cpu_spp > 0:
             out["cpu_baseline"] = cpu_baseline(args.scene, width, height, args.cpu_spp)
         print(json.dumps(out), flush=True)

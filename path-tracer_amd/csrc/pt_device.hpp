@@ -375,7 +375,7 @@ struct Best { int code; float lo, hi, a, b; };
 
 template <bool FAST, bool NEED_DIST>
 PT_DEV Hit closest_intersection(cfloat_p geom, int n_surfaces, V3 o, V3 d,
-                                unsigned long long *redo_count = nullptr)
+                                unsigned long long *redo_count = nullptr, const int *index_map = nullptr)
 {
     using N = Num<FAST>;
     const float INF = __builtin_inff();
@@ -383,7 +383,9 @@ PT_DEV Hit closest_intersection(cfloat_p geom, int n_surfaces, V3 o, V3 d,
     bool unsure = false;
     const V3 nd = -d;
     const float len_d = __builtin_amdgcn_sqrtf(N::dot(d, d));
-    for (int i = 0; i < n_surfaces; i++) {
+    for (int j = 0; j < n_surfaces; j++) {
+        // index_map (ascending scene indices) restricts the scan to a subset of the scene
+        const int i = index_map ? index_map[j] : j;
         cfloat_p g = geom + (size_t)i * GEOM_STRIDE;
         bool acc;           // surely a hit (FAST: a hit)
         bool rej;           // surely not a hit
@@ -463,7 +465,7 @@ PT_DEV Hit closest_intersection(cfloat_p geom, int n_surfaces, V3 o, V3 d,
         if (__any(unsure)) {                         // rare: redo those lanes directly
             if (unsure) {
                 if (redo_count) atomicAdd(redo_count, 1ull);
-                return closest_direct<false>(geom, n_surfaces, o, d);
+                return closest_direct<false>(geom, n_surfaces, o, d, index_map);
             }
         }
         if (h.idx >= 0) {

@@ -37,7 +37,7 @@ PT_DEV Hit closest_hit(const SceneView &sc, V3 o, V3 d, unsigned long long *redo
     if constexpr (KIND != SCENE_BVH) {
         return closest_intersection<FAST, NEED_DIST>(as_constant(sc.geom), sc.n_scan, o, d, redo_count);
     } else {
-        Hit h = closest_direct<FAST>(as_constant(sc.geom), sc.n_scan, o, d, sc.loose);
+        Hit h = closest_intersection<FAST, true>(as_constant(sc.geom), sc.n_scan, o, d, redo_count, sc.loose);
         if (h.idx < 0) h.dist = __builtin_inff();
         int stack[BVH_STACK];
         closest_in_bvh<FAST>(sc.bvh, o, d, h, stack, 1);
