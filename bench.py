@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--numeric", choices=["exact", "fast"], default="exact")
     ap.add_argument("--layout", choices=["megakernel", "wavefront"], default="megakernel")
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--cpu-spp", type=int, default=12,
+    ap.add_argument("--cpu-spp", type=int, default=32,
                     help="samples per pixel of the CPU baseline's bounded sample (0 = skip)")
     return ap.parse_args()
 

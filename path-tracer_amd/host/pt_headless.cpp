@@ -3,8 +3,8 @@
 // log() does (src/main.cpp:275-277), stop after a fixed number of passes (the
 // reference's -exit stops at 100) and write the tone-mapped image as a PPM.
 //
-//   pt_headless [-scene NAME] [-width W] [-height H] [-passes N] [-batch B]
-//               [-fast] [-out FILE.ppm]
+//   pt_headless [-scene NAME | -file SCENE.txt] [-width W] [-height H] [-passes N]
+//               [-batch B] [-fast] [-out FILE.ppm]
 //
 // -batch B > 0 renders B samples per pixel in one GPU call per pass through
 // pt::Renderer, keeping the sums on the device, instead of one sample per
@@ -12,10 +12,12 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <fstream>
 #include <iostream>
 #include <string>
 
 #include "pt_render.hpp"
+#include "pt_scene_io.hpp"
 #include "pt_scenes.hpp"
 
 static bool write_ppm(const std::string &path, int width, int height, const std::vector<uint8_t> &rgb)
@@ -30,7 +32,7 @@ static bool write_ppm(const std::string &path, int width, int height, const std:
 
 int main(int argc, char *argv[])
 {
-    std::string scene_name = "orange_plane", out;   // the reference's default scene (src/main.cpp:311)
+    std::string scene_name = "orange_plane", scene_file, out;   // the reference's default scene (src/main.cpp:311)
     int width = 356, height = 200, passes = 100, batch = 0;
     bool fast = false;
     for (int i = 1; i < argc; i++) {
@@ -40,6 +42,7 @@ int main(int argc, char *argv[])
             return argv[++i];
         };
         if (a == "-scene") scene_name = next("-scene");
+        else if (a == "-file") scene_file = next("-file");
         else if (a == "-width") width = std::atoi(next("-width"));
         else if (a == "-height") height = std::atoi(next("-height"));
         else if (a == "-passes") passes = std::atoi(next("-passes"));
@@ -53,7 +56,13 @@ int main(int argc, char *argv[])
     try {
         set_screen_size(width, height);
         std::optional<Scene> scene;
-        if (!Scenes::by_name(scene_name.c_str(), scene)) {
+        if (!scene_file.empty()) {
+            std::ifstream in(scene_file);
+            if (!in) { std::cerr << "cannot open " << scene_file << std::endl; return 2; }
+            try { scene.emplace(pt::load_scene(in)); }
+            catch (const pt::SceneFileError &e) { std::cerr << e.what() << std::endl; return 2; }
+            scene_name = scene_file;
+        } else if (!Scenes::by_name(scene_name.c_str(), scene)) {
             std::cerr << "unknown scene " << scene_name << std::endl;
             return 2;
         }

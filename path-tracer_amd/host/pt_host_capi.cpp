@@ -1,7 +1,10 @@
 // C entry points over the C++ host scene model, so that non-C++ hosts (the
 // Python tests and the benchmark driver) build scenes through the same code a
 // C++ caller uses: Scenes::*, Camera's matrix, pt::flatten.
+#include <fstream>
+
 #include "pt_render.hpp"
+#include "pt_scene_io.hpp"
 #include "pt_scenes.hpp"
 
 extern "C" {
@@ -29,6 +32,59 @@ int pt_host_builtin_scene(const char *name, int width, int height, pt_surface *s
     std::memcpy(bg, flat.bg, sizeof flat.bg);
     *camera = flat.camera;
     return 0;
+}
+
+namespace {
+thread_local std::string g_host_error;
+
+int emit(const Scene &scene, int width, int height, pt_surface *surfaces, pt_material *materials,
+         int32_t capacity, int32_t *n_surfaces, float bg[3], pt_camera *camera)
+{
+    const pt::FlatScene flat = pt::flatten(scene, width, height);
+    *n_surfaces = static_cast<int32_t>(flat.surfaces.size());
+    std::memcpy(bg, flat.bg, sizeof flat.bg);
+    *camera = flat.camera;
+    if (*n_surfaces > capacity) return -2;
+    for (size_t i = 0; i < flat.surfaces.size(); i++) {
+        surfaces[i] = flat.surfaces[i];
+        materials[i] = flat.materials[i];
+    }
+    return 0;
+}
+}  // namespace
+
+const char *pt_host_last_error(void) { return g_host_error.c_str(); }
+
+// Loads a scene file (pt_scene_io.hpp) and flattens it like pt_host_builtin_scene.
+// Returns 0, -2 if capacity is too small (*n_surfaces set), -3 if the file cannot
+// be read or parsed (pt_host_last_error has the message).
+int pt_host_load_scene(const char *path, int width, int height, pt_surface *surfaces,
+                       pt_material *materials, int32_t capacity, int32_t *n_surfaces,
+                       float bg[3], pt_camera *camera)
+{
+    set_screen_size(width, height);
+    try {
+        std::ifstream in(path);
+        if (!in) throw std::runtime_error(std::string("cannot open ") + path);
+        const Scene scene = pt::load_scene(in);
+        return emit(scene, width, height, surfaces, materials, capacity, n_surfaces, bg, camera);
+    } catch (const std::exception &e) {
+        g_host_error = e.what();
+        return -3;
+    }
+}
+
+// Writes scene `name` (Scenes::by_name, built for a width x height image) as a scene file.
+// Returns 0, -1 for an unknown name, -3 if the file cannot be written.
+int pt_host_save_scene(const char *name, int width, int height, const char *path)
+{
+    set_screen_size(width, height);
+    std::optional<Scene> scene;
+    if (!Scenes::by_name(name, scene)) return -1;
+    std::ofstream out(path);
+    if (!out) { g_host_error = std::string("cannot write ") + path; return -3; }
+    pt::save_scene(*scene, out);
+    return out.good() ? 0 : -3;
 }
 
 // Camera pose -> rotation matrix through class Camera (src/camera.hpp:20-39).

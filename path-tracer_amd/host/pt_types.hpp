@@ -186,6 +186,20 @@ class Camera {
         update();
     }
 
+    // A camera with exactly this stored pose (no OFFSET added): for restoring
+    // a pose read back with get_position/get_rotation.  Not in the reference.
+    static Camera from_pose(vec3 pos_, vec2 rot_, float focal_length_)
+    {
+        Camera c;
+        c.pos = pos_;
+        c.rot = rot_;
+        c.focal_length = focal_length_;
+        c.dirty = true;
+        c.update_rotation_matrix();
+        c.dirty = false;
+        return c;
+    }
+
     void rotate(float dx, float dy)
     {
         if (dx == 0 && dy == 0) return;

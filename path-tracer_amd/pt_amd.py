@@ -141,6 +141,35 @@ def builtin_scene(name, width, height):
     return SceneData(surf[:n.value], mats[:n.value], bg, cam)
 
 
+def load_scene_file(path, width, height):
+    """A scene file (host/pt_scene_io.hpp) through the C++ host mirror, flattened."""
+    host = load_host()
+    host.pt_host_last_error.restype = C.c_char_p
+    bg = np.zeros(3, dtype=np.float32)
+    cam = np.zeros(1, dtype=CAMERA)
+    n = C.c_int32(0)
+    rc = host.pt_host_load_scene(str(path).encode(), int(width), int(height), None, None, C.c_int32(0),
+                                 C.byref(n), _p(bg), _p(cam))
+    if rc == -3:
+        raise ValueError(host.pt_host_last_error().decode())
+    surf = np.zeros(max(n.value, 1), dtype=SURFACE)
+    mats = np.zeros(max(n.value, 1), dtype=MATERIAL)
+    rc = host.pt_host_load_scene(str(path).encode(), int(width), int(height), _p(surf), _p(mats),
+                                 C.c_int32(len(surf)), C.byref(n), _p(bg), _p(cam))
+    if rc != 0:
+        raise ValueError(host.pt_host_last_error().decode())
+    return SceneData(surf[:n.value], mats[:n.value], bg, cam)
+
+
+def save_scene_file(name, width, height, path):
+    """Writes built-in or synthetic scene `name` as a scene file."""
+    rc = load_host().pt_host_save_scene(name.encode(), int(width), int(height), str(path).encode())
+    if rc == -1:
+        raise KeyError("unknown scene %r" % name)
+    if rc != 0:
+        raise OSError("cannot write %s" % path)
+
+
 class Context:
     """One GPU's render context (pt_ctx)."""
 

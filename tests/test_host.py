@@ -39,3 +39,55 @@ def test_camera_matrix_equals_oracle(pt, orc):
             host.pt_host_camera_matrix(C.c_float(rx), C.c_float(ry), off, C.c_void_p(out.ctypes.data))
             want = orc.camera_init([0, 0, 0], rx, ry, 1.0, off, 8, 8)["rot"][0]
             assert out.tobytes() == want.tobytes(), (rx, ry, off)
+
+
+def test_scene_files_round_trip(pt, tmp_path):
+    """save_scene -> load_scene reproduces every flattened scene bit for bit."""
+    for name in list(pt.SCENE_NAMES) + ["glass_stress", "heightfield:12"]:
+        path = tmp_path / (name.replace(":", "_") + ".txt")
+        pt.save_scene_file(name, 320, 200, path)
+        a, b = pt.builtin_scene(name, 320, 200), pt.load_scene_file(path, 320, 200)
+        assert a.surfaces.tobytes() == b.surfaces.tobytes(), name
+        assert a.materials.tobytes() == b.materials.tobytes(), name
+        assert a.bg.tobytes() == b.bg.tobytes() and a.camera.tobytes() == b.camera.tobytes(), name
+
+
+def test_scene_file_by_hand(pt, orc, tmp_path):
+    path = tmp_path / "hand.txt"
+    path.write_text("""# two surfaces
+camera 0 0 -3  0 0  auto
+background 0.1 0.2 0.3
+dof 0.25 4
+material red diffuse 1 0.05 0.05
+material lamp diffuse 1 1 1  2 2 2     # emissive
+material glass glass 1 1 1
+sphere 0 0 0 0.5 glass
+triangle -2 1 -1  0 1 10  2 1 -1 red
+sphere 0 -3 0 1 lamp
+""")
+    sc = pt.load_scene_file(path, 64, 48)
+    assert len(sc.surfaces) == 3 and list(sc.surfaces["kind"]) == [pt.SPHERE, pt.TRIANGLE, pt.SPHERE]
+    assert list(sc.materials["type"]) == [pt.GLASS, pt.DIFFUSE, pt.DIFFUSE]
+    assert np.allclose(sc.materials["emittance"][2], 2) and np.allclose(sc.bg, [0.1, 0.2, 0.3])
+    cam = sc.camera[0]
+    assert cam["focal"] == 48 and cam["dof_on"] == 1 and cam["dof_aperture"] == np.float32(0.25)
+    # the plain camera statement adds OFFSET, as the reference's constructor does
+    want = orc.camera_init([0, 0, -3], 0, 0, 48, 1, 64, 48)["rot"][0]
+    assert cam["rot"].tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("text,fragment", [
+    ("sphere 0 0 0 1 nomat\ncamera 0 0 0 0 0 auto\n", "unknown material"),
+    ("camera 0 0 0 0 0 auto\nmaterial m plastic 1 1 1\n", "unknown material type"),
+    ("camera 0 0 0 0 0 auto\ntriangle 0 0 0 1 1 1 m\n", "too few"),
+    ("background 0 0 0\n", "no camera"),
+    ("camera 0 0 0 0 0 auto\nteapot 1 2 3\n", "unknown statement"),
+])
+def test_scene_file_errors(pt, tmp_path, text, fragment):
+    path = tmp_path / "bad.txt"
+    path.write_text(text)
+    with pytest.raises(ValueError) as e:
+        pt.load_scene_file(path, 32, 32)
+    assert fragment in str(e.value) and "line" in str(e.value)
+    with pytest.raises(ValueError):
+        pt.load_scene_file(tmp_path / "missing.txt", 32, 32)
