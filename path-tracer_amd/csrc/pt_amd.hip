@@ -273,6 +273,14 @@ SceneView scene_view(const pt_ctx *ctx)
     return v;
 }
 
+// Dynamic LDS a kernel of scene kind KIND needs: the shading records, or the traversal stacks.
+size_t lds_bytes_for(const pt_ctx *ctx, int kind)
+{
+    if (kind == SCENE_LDS) return (size_t)ctx->n_surfaces * SHADE_STRIDE * sizeof(float);
+    if (kind == SCENE_BVH) return BVH_STACK_IN_LDS ? (size_t)BVH_STACK * BLOCK * sizeof(int) : 0;
+    return 0;
+}
+
 int scene_kind(const pt_ctx *ctx)
 {
     if (ctx->n_bvh > 0) return SCENE_BVH;
@@ -297,7 +305,7 @@ template <bool FAST, int KIND>
 int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample, uint64_t seed)
 {
     const uint32_t n_pixels = (uint32_t)ctx->cam.width * (uint32_t)ctx->cam.height;
-    const size_t lds_bytes = KIND == SCENE_LDS ? (size_t)ctx->n_surfaces * SHADE_STRIDE * sizeof(float) : 0;
+    const size_t lds_bytes = lds_bytes_for(ctx, KIND);
 
     int blocks_per_cu = 0;
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, (k_render_mega<FAST, KIND>), BLOCK, lds_bytes));
@@ -415,7 +423,7 @@ int launch_wavefront(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sam
     P.n_pixels = n_pixels;
     P.result = result;
     P.stats = reinterpret_cast<unsigned long long *>(ctx->d_queue + 2);
-    const size_t lds_bytes = KIND == SCENE_LDS ? (size_t)ctx->n_surfaces * SHADE_STRIDE * sizeof(float) : 0;
+    const size_t lds_bytes = lds_bytes_for(ctx, KIND);
     std::vector<uint32_t> counts(WF_COUNT_WORDS);
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 32, ctx->stream));
@@ -769,7 +777,7 @@ int pt_primary_hits(pt_ctx *ctx, int32_t *surf_idx, float *distance, int numeric
     if ((rc = dev_alloc(ctx, &d_idx.p, (size_t)n))) return rc;
     if ((rc = dev_alloc(ctx, &d_dist.p, (size_t)n))) return rc;
     rc = with_variant((numeric & PT_NUM_FAST) != 0, scene_kind(ctx), [&]<bool FAST, int KIND>() {
-        hipLaunchKernelGGL((k_primary_hits<FAST, KIND>), dim3(blocks_for(n)), dim3(BLOCK), 0, ctx->stream,
+        hipLaunchKernelGGL((k_primary_hits<FAST, KIND>), dim3(blocks_for(n)), dim3(BLOCK), lds_bytes_for(ctx, KIND), ctx->stream,
                            ctx->cam, scene_view(ctx), d_idx.p, d_dist.p);
         return PT_OK;
     });
@@ -796,7 +804,7 @@ int pt_intersect_rays(pt_ctx *ctx, const float *origin, const float *dir, int64_
     if ((rc = dev_alloc(ctx, &d_dist.p, (size_t)n))) return rc;
     if ((rc = dev_alloc(ctx, &d_pt.p, (size_t)n * 3))) return rc;
     rc = with_variant((numeric & PT_NUM_FAST) != 0, scene_kind(ctx), [&]<bool FAST, int KIND>() {
-        hipLaunchKernelGGL((k_intersect_rays<FAST, KIND>), dim3(blocks_for(n)), dim3(BLOCK), 0, ctx->stream,
+        hipLaunchKernelGGL((k_intersect_rays<FAST, KIND>), dim3(blocks_for(n)), dim3(BLOCK), lds_bytes_for(ctx, KIND), ctx->stream,
                            scene_view(ctx), d_o.p, d_d.p, (long long)n, d_idx.p, d_dist.p, d_pt.p);
         return PT_OK;
     });

@@ -31,16 +31,23 @@ constexpr int SCENE_LDS = 0;      // shading records staged in LDS, linear scan
 constexpr int SCENE_GLOBAL = 1;   // shading records read from global memory, linear scan
 constexpr int SCENE_BVH = 2;      // shading records from global memory, scan + hierarchy
 
+// lds: the kernel's dynamic LDS; a hierarchy scene keeps the traversal stacks
+// there, BVH_STACK levels of BLOCK lanes (level-major, so a level's 64 lanes
+// fall in 64 different banks).
 template <bool FAST, bool NEED_DIST, int KIND>
-PT_DEV Hit closest_hit(const SceneView &sc, V3 o, V3 d, unsigned long long *redo_count = nullptr)
+PT_DEV Hit closest_hit(const SceneView &sc, V3 o, V3 d, float *lds, unsigned long long *redo_count = nullptr)
 {
     if constexpr (KIND != SCENE_BVH) {
         return closest_intersection<FAST, NEED_DIST>(as_constant(sc.geom), sc.n_scan, o, d, redo_count);
     } else {
         Hit h = closest_intersection<FAST, true>(as_constant(sc.geom), sc.n_scan, o, d, redo_count, sc.loose);
         if (h.idx < 0) h.dist = __builtin_inff();
-        int stack[BVH_STACK];
-        closest_in_bvh<FAST>(sc.bvh, o, d, h, stack, 1);
+        if constexpr (BVH_STACK_IN_LDS) {
+            closest_in_bvh<FAST>(sc.bvh, o, d, h, reinterpret_cast<int *>(lds) + threadIdx.x, BLOCK);
+        } else {
+            int stack[BVH_STACK];
+            closest_in_bvh<FAST>(sc.bvh, o, d, h, stack, 1);
+        }
         if (h.idx < 0) h.dist = 0.0f;
         return h;
     }
@@ -72,7 +79,8 @@ k_primary_hits(Camera cam, SceneView scene, int32_t *idx, float *dist)
     const int x = p % cam.width, y = p / cam.width;
     const V3 o = v3(cam.pos[0], cam.pos[1], cam.pos[2]);
     const V3 d = ray_direction_by_pixel<FAST>(cam, (float)x, (float)y);
-    const Hit h = closest_hit<FAST, true, KIND>(scene, o, d);
+    extern __shared__ __align__(16) float lds[];
+    const Hit h = closest_hit<FAST, true, KIND>(scene, o, d, lds);
     idx[p] = h.idx;
     dist[p] = h.idx < 0 ? 0.0f : h.dist;
 }
@@ -86,7 +94,8 @@ k_intersect_rays(SceneView scene, const float *org, const float *dir,
     if (i >= n) return;
     const V3 o = v3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
     const V3 d = v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
-    const Hit h = closest_hit<FAST, true, KIND>(scene, o, d);
+    extern __shared__ __align__(16) float lds[];
+    const Hit h = closest_hit<FAST, true, KIND>(scene, o, d, lds);
     idx[i] = h.idx;
     dist[i] = h.idx < 0 ? 0.0f : h.dist;
     V3 pt = v3(0, 0, 0);
@@ -182,12 +191,13 @@ PT_DEV void path_begin(PathState &ps, const Camera &cam, uint32_t pixel_key, uin
 // in double, which no fp32 path matches bit for bit, and they are checked to
 // 1e-5 instead.
 template <bool FAST, int KIND>
-PT_DEV bool path_segment(PathState &ps, const SceneView &sc, const float *shade, unsigned long long *redo_count)
+PT_DEV bool path_segment(PathState &ps, const SceneView &sc, const float *shade, float *lds,
+                         unsigned long long *redo_count)
 {
     using N = Num<FAST>;
     using S = Num<true>;
     const float (&bg)[3] = sc.bg;
-    const Hit h = closest_hit<FAST, false, KIND>(sc, ps.o, ps.d, redo_count);
+    const Hit h = closest_hit<FAST, false, KIND>(sc, ps.o, ps.d, lds, redo_count);
     if (h.idx < 0) {                                // main.cpp:105-108
         ps.col = v3(S::mad(bg[0], ps.thr.x, ps.col.x), S::mad(bg[1], ps.thr.y, ps.col.y),
                     S::mad(bg[2], ps.thr.z, ps.col.z));
@@ -316,7 +326,7 @@ k_render_mega(RenderParams P)
             path_begin(ps, P.cam, pixel_key, s, px, py);
             need_path = false;
         }
-        const bool ended = path_segment<FAST, KIND>(ps, P.scene, shade, P.stats + 1);
+        const bool ended = path_segment<FAST, KIND>(ps, P.scene, shade, lds_shade, P.stats + 1);
         n_seg++;
         if (ended) {
             sum = sum + ps.col;                 // buffer[u][v] += color, main.cpp:139
@@ -427,7 +437,7 @@ k_wf_bounce(WfParams P)
         ps.rng.ctr = d.y;
         ps.depth = (int)d.z;
         slot = d.w;
-        const bool ended = path_segment<FAST, KIND>(ps, P.scene, shade, P.stats + 1);
+        const bool ended = path_segment<FAST, KIND>(ps, P.scene, shade, lds_shade, P.stats + 1);
         if (ended) {
             float *r = P.result + 3ull * slot;
             r[0] = ps.col.x; r[1] = ps.col.y; r[2] = ps.col.z;
