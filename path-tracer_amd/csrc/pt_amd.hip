@@ -307,8 +307,11 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
     const uint32_t n_pixels = (uint32_t)ctx->cam.width * (uint32_t)ctx->cam.height;
     const size_t lds_bytes = lds_bytes_for(ctx, KIND);
 
+    // scenes with a hierarchy have a megakernel of their own
+    void (*kernel)(RenderParams) = &k_render_mega<FAST, KIND>;
+    if constexpr (KIND == SCENE_BVH) kernel = &k_render_mega_bvh<FAST>;
     int blocks_per_cu = 0;
-    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, (k_render_mega<FAST, KIND>), BLOCK, lds_bytes));
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, BLOCK, lds_bytes));
     if (blocks_per_cu < 1) return fail(ctx, PT_E_HIP, "render kernel does not fit on a compute unit");
     const uint32_t grid = (uint32_t)blocks_per_cu * (uint32_t)ctx->num_cus;
     const uint64_t lanes = (uint64_t)grid * BLOCK;
@@ -348,7 +351,7 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 32, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    hipLaunchKernelGGL((k_render_mega<FAST, KIND>), dim3(grid), dim3(BLOCK), lds_bytes, ctx->stream, P);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), lds_bytes, ctx->stream, P);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     const size_t n = (size_t)n_pixels * 3;
@@ -358,7 +361,7 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
 
     hipFuncAttributes attr{};
-    HIP_TRY(ctx, hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_render_mega<FAST, KIND>)));
+    HIP_TRY(ctx, hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(kernel)));
     ctx->last = pt_counters{};
     ctx->last.samples = (uint64_t)n_pixels * spp;
     ctx->last.vgprs = (uint32_t)attr.numRegs;

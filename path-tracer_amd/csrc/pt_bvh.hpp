@@ -187,84 +187,106 @@ PT_DEV float box_entry(float4 bmin, float4 bmax, V3 o, V3 inv, float t_far)
     return t_in <= t_out ? t_in : -1.0f;
 }
 
-// Continues a closest-hit search through the hierarchy.  On entry `best` is
-// the exact closest hit among the surfaces outside the hierarchy (idx < 0:
-// none, dist = +inf); on exit it is the closest hit overall, with the
-// reference's t and distance.  stack: BVH_STACK ints per lane, lane-strided
-// (stack[level * stride]).
+// A lane's traversal in progress.
+struct BvhCursor {
+    V3 inv;              // 1/d per component
+    float len_d, inv_len;
+    int node;            // >= 0: internal node to open; < 0: leaf ~node to test
+    int sp;              // entries on the stack
+};
+
 template <bool FAST>
-PT_DEV void closest_in_bvh(const BvhView &bvh, V3 o, V3 d, Hit &best, int *stack, int stride)
+PT_DEV void bvh_begin(BvhCursor &c, const BvhView &bvh, V3 d)
+{
+    c.inv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    c.len_d = __builtin_amdgcn_sqrtf(Num<FAST>::dot(d, d));
+    c.inv_len = __builtin_amdgcn_rcpf(c.len_d);
+    c.sp = 0;
+    c.node = bvh.n_leaves > 1 ? 0 : ~0;
+}
+
+// Advances a traversal by one node or one leaf.  `best` is the exact closest
+// hit so far (idx < 0: none, dist = +inf).  Returns false when the traversal
+// is complete.  stack: BVH_STACK ints per lane, lane-strided (stack[level * stride]).
+template <bool FAST>
+PT_DEV bool bvh_step(BvhCursor &c, const BvhView &bvh, V3 o, V3 d, Hit &best, int *stack, int stride)
 {
     using N = Num<FAST>;
-    const V3 nd = -d;
-    const V3 inv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-    const float len_d = __builtin_amdgcn_sqrtf(N::dot(d, d));
-    const float inv_len = __builtin_amdgcn_rcpf(len_d);
-    int sp = 0;
-    int node = bvh.n_leaves > 1 ? 0 : ~0;
-    for (;;) {
-        if (node >= 0) {
-            const float4 *q = bvh.nodes + (size_t)node * BVH_NODE_QUADS;
-            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-            // nothing beyond the best distance can win; the margin covers the rounding of t * |d|
-            const float t_far = best.dist * inv_len * (1.0f + 1e-5f);
-            const float tl = box_entry(q0, q1, o, inv, t_far);
-            const float tr = box_entry(q2, q3, o, inv, t_far);
-            const int left = __float_as_int(q0.w), right = __float_as_int(q1.w);
-            if (tl >= 0.0f && tr >= 0.0f) {                 // both: nearer first
-                const bool left_first = tl <= tr;
-                stack[sp * stride] = left_first ? right : left;
-                sp++;
-                node = left_first ? left : right;
-                continue;
-            }
-            if (tl >= 0.0f) { node = left; continue; }
-            if (tr >= 0.0f) { node = right; continue; }
+    if (c.node >= 0) {
+        const float4 *q = bvh.nodes + (size_t)c.node * BVH_NODE_QUADS;
+        const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        // nothing beyond the best distance can win; the margin covers the rounding of t * |d|
+        const float t_far = best.dist * c.inv_len * (1.0f + 1e-5f);
+        const float tl = box_entry(q0, q1, o, c.inv, t_far);
+        const float tr = box_entry(q2, q3, o, c.inv, t_far);
+        const int left = __float_as_int(q0.w), right = __float_as_int(q1.w);
+        if (tl >= 0.0f && tr >= 0.0f) {                 // both: nearer first
+            const bool left_first = tl <= tr;
+            stack[c.sp * stride] = left_first ? right : left;
+            c.sp++;
+            c.node = left_first ? left : right;
+            return true;
+        }
+        if (tl >= 0.0f) { c.node = left; return true; }
+        if (tr >= 0.0f) { c.node = right; return true; }
+    } else {
+        const V3 nd = -d;
+        const float *g = bvh.leaves + (size_t)(~c.node) * GEOM_STRIDE;
+        const float4 g0 = *reinterpret_cast<const float4 *>(g);
+        const float4 g1 = *reinterpret_cast<const float4 *>(g + 4);
+        const float4 g2 = *reinterpret_cast<const float4 *>(g + 8);
+        const int idx = __float_as_int(g0.w);
+        const TriDets q = triangle_dets_v<FAST>(v3(g0.x, g0.y, g0.z), v3(g1.x, g1.y, g1.z), g1.w,
+                                                v3(g2.x, g2.y, g2.z), o, nd);
+        const float rinv = __builtin_amdgcn_rcpf(q.det_a);
+        const float u = q.du * rinv, v = q.dv * rinv, t = q.dt * rinv;
+        const float s = u + v;
+        const bool det_bad = q.det_a >= -EPS_F && q.det_a <= EPS_F;
+        if constexpr (FAST) {
+            const bool acc = !(det_bad | (u < -EPS_F) | (u >= 1.0f) | (v < -EPS_F) | (s >= 1.0f) | (t <= EPS_F));
+            const float dist = t * c.len_d;
+            if (acc & (dist < best.dist)) { best.idx = idx; best.t = t; best.dist = dist; }
         } else {
-            const float *g = bvh.leaves + (size_t)(~node) * GEOM_STRIDE;
-            const float4 g0 = *reinterpret_cast<const float4 *>(g);
-            const float4 g1 = *reinterpret_cast<const float4 *>(g + 4);
-            const float4 g2 = *reinterpret_cast<const float4 *>(g + 8);
-            const int idx = __float_as_int(g0.w);
-            const TriDets q = triangle_dets_v<FAST>(v3(g0.x, g0.y, g0.z), v3(g1.x, g1.y, g1.z), g1.w,
-                                                    v3(g2.x, g2.y, g2.z), o, nd);
-            const float rinv = __builtin_amdgcn_rcpf(q.det_a);
-            const float u = q.du * rinv, v = q.dv * rinv, t = q.dt * rinv;
-            const float s = u + v;
-            const bool det_bad = q.det_a >= -EPS_F && q.det_a <= EPS_F;
-            if constexpr (FAST) {
-                const bool acc = !(det_bad | (u < -EPS_F) | (u >= 1.0f) | (v < -EPS_F) | (s >= 1.0f) | (t <= EPS_F));
-                const float dist = t * len_d;
-                if (acc & (dist < best.dist)) { best.idx = idx; best.t = t; best.dist = dist; }
-            } else {
-                const bool rej = det_bad | (u < BAND_LO_REJ) | (u > BAND_ONE_REJ) | (v < BAND_LO_REJ) |
-                                 (s > BAND_ONE_REJ) | (t < BAND_T_REJ);
-                // a sure hit farther than the best, by more than the error of the estimate, cannot win
-                const bool farther = t * len_d * (1.0f - TRI_DIST_ERR) > best.dist;
-                if (!(rej | farther)) {
-                    // exact evaluation, as Triangle::intersects does it (src/surface.hpp:53-70)
-                    bool ok = !det_bad;
-                    const float ue = q.du / q.det_a;
-                    ok = ok & !(ue < -EPS_F || ue >= 1.0f);
-                    const float ve = q.dv / q.det_a;
-                    ok = ok & !(ve < -EPS_F || ue + ve >= 1.0f);
-                    const float te = q.dt / q.det_a;
-                    ok = ok & !(te <= EPS_F);
-                    const V3 td = d * te;
-                    const float dist = __builtin_sqrtf(N::dot(td, td));
-                    // smallest distance wins; equal distances: the earlier surface in scene order
-                    if (ok & ((dist < best.dist) | ((dist == best.dist) & (idx < best.idx) & (best.idx >= 0)))) {
-                        best.idx = idx;
-                        best.t = te;
-                        best.dist = dist;
-                    }
+            const bool rej = det_bad | (u < BAND_LO_REJ) | (u > BAND_ONE_REJ) | (v < BAND_LO_REJ) |
+                             (s > BAND_ONE_REJ) | (t < BAND_T_REJ);
+            // a sure hit farther than the best, by more than the error of the estimate, cannot win
+            const bool farther = t * c.len_d * (1.0f - TRI_DIST_ERR) > best.dist;
+            if (!(rej | farther)) {
+                // exact evaluation, as Triangle::intersects does it (src/surface.hpp:53-70)
+                bool ok = !det_bad;
+                const float ue = q.du / q.det_a;
+                ok = ok & !(ue < -EPS_F || ue >= 1.0f);
+                const float ve = q.dv / q.det_a;
+                ok = ok & !(ve < -EPS_F || ue + ve >= 1.0f);
+                const float te = q.dt / q.det_a;
+                ok = ok & !(te <= EPS_F);
+                const V3 td = d * te;
+                const float dist = __builtin_sqrtf(N::dot(td, td));
+                // smallest distance wins; equal distances: the earlier surface in scene order
+                if (ok & ((dist < best.dist) | ((dist == best.dist) & (idx < best.idx) & (best.idx >= 0)))) {
+                    best.idx = idx;
+                    best.t = te;
+                    best.dist = dist;
                 }
             }
         }
-        if (sp == 0) break;
-        sp--;
-        node = stack[sp * stride];
     }
+    if (c.sp == 0) return false;
+    c.sp--;
+    c.node = stack[c.sp * stride];
+    return true;
+}
+
+// Continues a closest-hit search through the hierarchy.  On entry `best` is
+// the exact closest hit among the surfaces outside the hierarchy (idx < 0:
+// none, dist = +inf); on exit it is the closest hit overall, with the
+// reference's t and distance.
+template <bool FAST>
+PT_DEV void closest_in_bvh(const BvhView &bvh, V3 o, V3 d, Hit &best, int *stack, int stride)
+{
+    BvhCursor c;
+    bvh_begin<FAST>(c, bvh, d);
+    while (bvh_step<FAST>(c, bvh, o, d, best, stack, stride)) {}
 }
 
 }  // namespace ptd

@@ -178,9 +178,10 @@ PT_DEV void path_begin(PathState &ps, const Camera &cam, uint32_t pixel_key, uin
     ps.depth = 0;
 }
 
-// One iteration of trace_ray's loop, src/main.cpp:84-109.  Returns true when the
+// One iteration of trace_ray's loop, src/main.cpp:84-109, in two parts: the
+// closest hit (closest_hit), then shade_hit below, which returns true when the
 // path has ended (ps.col is then its radiance).  shade = the scene's shading
-// records (LDS).
+// records (LDS or global memory).
 //
 // FAST selects the arithmetic of the closest-hit search and of the hit point:
 // EXACT finds, for every ray, the surface and parameter t the reference's
@@ -190,14 +191,12 @@ PT_DEV void path_begin(PathState &ps, const Camera &cam, uint32_t pixel_key, uin
 // (each within 1 ulp) in both modes: the reference evaluates them through libm
 // in double, which no fp32 path matches bit for bit, and they are checked to
 // 1e-5 instead.
-template <bool FAST, int KIND>
-PT_DEV bool path_segment(PathState &ps, const SceneView &sc, const float *shade, float *lds,
-                         unsigned long long *redo_count)
+template <bool FAST>
+PT_DEV bool shade_hit(PathState &ps, const SceneView &sc, const float *shade, const Hit &h)
 {
     using N = Num<FAST>;
     using S = Num<true>;
     const float (&bg)[3] = sc.bg;
-    const Hit h = closest_hit<FAST, false, KIND>(sc, ps.o, ps.d, lds, redo_count);
     if (h.idx < 0) {                                // main.cpp:105-108
         ps.col = v3(S::mad(bg[0], ps.thr.x, ps.col.x), S::mad(bg[1], ps.thr.y, ps.col.y),
                     S::mad(bg[2], ps.thr.z, ps.col.z));
@@ -235,6 +234,85 @@ PT_DEV bool path_segment(PathState &ps, const SceneView &sc, const float *shade,
     return ended;
 }
 
+template <bool FAST, int KIND>
+PT_DEV bool path_segment(PathState &ps, const SceneView &sc, const float *shade, float *lds,
+                         unsigned long long *redo_count)
+{
+    const Hit h = closest_hit<FAST, false, KIND>(sc, ps.o, ps.d, lds, redo_count);
+    return shade_hit<FAST>(ps, sc, shade, h);
+}
+
+// ---------------------------------------------------------------- work queue
+
+// A wave's share of the global work queue: items [next, end) already taken
+// from the queue head and not yet handed to a lane.  All fields are equal in
+// every live lane of the wave.
+struct WorkPool { uint32_t next, end; bool drained; };
+
+// Hands one work item to every lane with want = true, refilling the pool with
+// POOL_BATCH items from the global head when it runs short (one atomic per
+// refill).  Must be called by every live lane of the wave together.  Returns
+// NO_ITEM to a lane once the queue is empty.
+PT_DEV uint32_t pool_take(WorkPool &pool, bool want, uint32_t *queue_head, uint32_t n_items)
+{
+    const uint32_t lane = __lane_id();
+    const unsigned long long mask = __ballot(want);
+    uint32_t cnt = (uint32_t)__popcll(mask);
+    const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    uint32_t got = NO_ITEM;
+    const uint32_t avail = pool.end - pool.next;
+    if (want && rank < avail) got = pool.next + rank;
+    if (cnt <= avail) {
+        pool.next += cnt;
+        return got;
+    }
+    cnt -= avail;                               // 1..64 lanes still without an item
+    uint32_t base = n_items;
+    if (!pool.drained) {
+        uint32_t b = 0;
+        if (lane == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) b = atomicAdd(queue_head, POOL_BATCH);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+    }
+    uint32_t end = base + POOL_BATCH;
+    if (base >= n_items) { base = end = n_items; pool.drained = true; }
+    else if (end > n_items) end = n_items;
+    if (want && rank >= avail && base + (rank - avail) < end) got = base + (rank - avail);
+    pool.next = base + cnt < end ? base + cnt : end;
+    pool.end = end;
+    return got;
+}
+
+// What a lane keeps about its current work item (pixel, chunk of samples).
+struct ItemState {
+    bool have;
+    uint32_t item, pixel, pixel_key, s, s_end;
+    int px, py;
+    V3 sum;
+};
+
+PT_DEV void item_open(ItemState &it, uint32_t item, const Camera &cam, uint32_t n_pixels, uint32_t first_sample,
+                      uint32_t spp, uint32_t chunk_len, uint32_t seed_mix)
+{
+    it.item = item;
+    it.have = true;
+    const uint32_t chunk = item / n_pixels;
+    it.pixel = item - chunk * n_pixels;
+    it.px = (int)(it.pixel % (uint32_t)cam.width);
+    it.py = (int)(it.pixel / (uint32_t)cam.width);
+    it.s = first_sample + chunk * chunk_len;
+    const uint32_t last = first_sample + spp;
+    it.s_end = it.s + chunk_len < last ? it.s + chunk_len : last;
+    it.sum = v3(0, 0, 0);
+    it.pixel_key = rng_pixel(seed_mix, it.pixel);
+}
+
+PT_DEV void item_close(ItemState &it, float *slabs)
+{
+    float *dst = slabs + 3ull * it.item;
+    dst[0] = it.sum.x; dst[1] = it.sum.y; dst[2] = it.sum.z;
+    it.have = false;
+}
+
 // ---------------------------------------------------------------- megakernel
 
 // Persistent lanes.  A lane owns one work item (pixel, chunk of samples) at a
@@ -261,77 +339,102 @@ k_render_mega(RenderParams P)
         shade = lds_shade;
     }
 
-    const uint32_t lane = __lane_id();
-    const unsigned long long lanes_below = (1ull << lane) - 1ull;
-
-    // wave-uniform work pool [pool_next, pool_end)
-    uint32_t pool_next = 0, pool_end = 0;
-    bool drained = false;
-
-    bool have_item = false, need_path = true;
-    uint32_t item = 0, pixel = 0, pixel_key = 0, s = 0, s_end = 0;
-    int px = 0, py = 0;
-    V3 sum = v3(0, 0, 0);
+    WorkPool pool = {0, 0, false};
+    ItemState it = {false, 0, 0, 0, 0, 0, 0, 0, v3(0, 0, 0)};
+    bool need_path = true;
     PathState ps = {v3(0, 0, 0), v3(0, 0, 1), v3(1, 1, 1), v3(0, 0, 0), {0, 0}, 0};
     unsigned long long n_seg = 0;
 
     for (;;) {
-        const bool want = need_path && s == s_end;
+        const bool want = need_path && it.s == it.s_end;
         if (__any(want)) {                      // wave-uniform: every live lane enters
-            if (want && have_item) {
-                float *dst = P.slabs + 3ull * item;
-                dst[0] = sum.x; dst[1] = sum.y; dst[2] = sum.z;
-                have_item = false;
-            }
-            const unsigned long long mask = __ballot(want);
-            uint32_t cnt = (uint32_t)__popcll(mask);
-            const uint32_t rank = (uint32_t)__popcll(mask & lanes_below);
-            uint32_t got = NO_ITEM;
-            const uint32_t avail = pool_end - pool_next;
-            if (want && rank < avail) got = pool_next + rank;
-            if (cnt <= avail) {
-                pool_next += cnt;
-            } else {
-                cnt -= avail;                   // 1..64 lanes still without an item
-                uint32_t base = P.n_items;
-                if (!drained) {
-                    uint32_t b = 0;
-                    if (lane == (uint32_t)__ffsll((long long)__ballot(1)) - 1u)
-                        b = atomicAdd(P.queue_head, POOL_BATCH);
-                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-                }
-                uint32_t end = base + POOL_BATCH;
-                if (base >= P.n_items) { base = end = P.n_items; drained = true; }
-                else if (end > P.n_items) end = P.n_items;
-                if (want && rank >= avail && base + (rank - avail) < end) got = base + (rank - avail);
-                pool_next = base + cnt < end ? base + cnt : end;
-                pool_end = end;
-            }
+            if (want && it.have) item_close(it, P.slabs);
+            const uint32_t got = pool_take(pool, want, P.queue_head, P.n_items);
             if (want) {
                 if (got == NO_ITEM) break;      // queue empty: this lane retires
-                item = got;
-                have_item = true;
-                const uint32_t chunk = item / P.n_pixels;
-                pixel = item - chunk * P.n_pixels;
-                px = (int)(pixel % (uint32_t)P.cam.width);
-                py = (int)(pixel / (uint32_t)P.cam.width);
-                s = P.first_sample + chunk * P.chunk_len;
-                const uint32_t last = P.first_sample + P.spp;
-                s_end = s + P.chunk_len < last ? s + P.chunk_len : last;
-                sum = v3(0, 0, 0);
-                pixel_key = rng_pixel(P.seed_mix, pixel);
+                item_open(it, got, P.cam, P.n_pixels, P.first_sample, P.spp, P.chunk_len, P.seed_mix);
             }
         }
         if (need_path) {
-            path_begin(ps, P.cam, pixel_key, s, px, py);
+            path_begin(ps, P.cam, it.pixel_key, it.s, it.px, it.py);
             need_path = false;
         }
         const bool ended = path_segment<FAST, KIND>(ps, P.scene, shade, lds_shade, P.stats + 1);
         n_seg++;
         if (ended) {
-            sum = sum + ps.col;                 // buffer[u][v] += color, main.cpp:139
-            s++;
+            it.sum = it.sum + ps.col;           // buffer[u][v] += color, main.cpp:139
+            it.s++;
             need_path = true;
+        }
+    }
+    atomicAdd(P.stats, n_seg);
+}
+
+// The megakernel for scenes with a hierarchy.  A traversal takes tens of
+// dependent steps whose number differs from lane to lane, so lanes are
+// decoupled at the granularity of one traversal step: a lane whose traversal
+// has finished waits until at least half of the wave's live lanes wait too;
+// then they all shade their hits, start their next segments (or paths, or
+// work items) and scan the surfaces outside the hierarchy together, while in
+// every iteration each traversing lane advances by one node or leaf.
+template <bool FAST>
+__global__ void __launch_bounds__(BLOCK)
+k_render_mega_bvh(RenderParams P)
+{
+    const float *shade = P.scene.shade;
+    WorkPool pool = {0, 0, false};
+    ItemState it = {false, 0, 0, 0, 0, 0, 0, 0, v3(0, 0, 0)};
+    PathState ps = {v3(0, 0, 0), v3(0, 0, 1), v3(1, 1, 1), v3(0, 0, 0), {0, 0}, 0};
+    Hit best = {-1, 0.0f, 0.0f};
+    BvhCursor cur;
+    cur.node = 0; cur.sp = 0; cur.inv = v3(0, 0, 0); cur.len_d = 1.0f; cur.inv_len = 1.0f;
+    int stack[BVH_STACK];
+    bool traversing = false;        // false: waiting to shade / start a segment
+    bool have_hit = false;          // a finished segment waits to be shaded
+    unsigned long long n_seg = 0;
+
+    for (;;) {
+        const unsigned long long waiting = __ballot(!traversing);
+        const unsigned long long live = __ballot(1);
+        if (2 * __popcll(waiting) >= __popcll(live)) {       // wave-uniform
+            bool need_path = false;
+            if (!traversing) {
+                need_path = !have_hit;
+                if (have_hit) {
+                    if (best.idx < 0) best.dist = 0.0f;
+                    if (shade_hit<FAST>(ps, P.scene, shade, best)) {
+                        it.sum = it.sum + ps.col;            // buffer[u][v] += color, main.cpp:139
+                        it.s++;
+                        need_path = true;
+                    }
+                    have_hit = false;
+                }
+            }
+            const bool want = need_path && it.s == it.s_end;
+            if (__any(want)) {
+                if (want && it.have) item_close(it, P.slabs);
+                const uint32_t got = pool_take(pool, want, P.queue_head, P.n_items);
+                if (want) {
+                    if (got == NO_ITEM) break;               // queue empty: this lane retires
+                    item_open(it, got, P.cam, P.n_pixels, P.first_sample, P.spp, P.chunk_len, P.seed_mix);
+                }
+            }
+            if (!traversing) {
+                if (need_path) path_begin(ps, P.cam, it.pixel_key, it.s, it.px, it.py);
+                // the surfaces outside the hierarchy first, then the hierarchy
+                best = closest_intersection<FAST, true>(as_constant(P.scene.geom), P.scene.n_scan, ps.o, ps.d,
+                                                        P.stats + 1, P.scene.loose);
+                if (best.idx < 0) best.dist = __builtin_inff();
+                bvh_begin<FAST>(cur, P.scene.bvh, ps.d);
+                traversing = true;
+                n_seg++;
+            }
+        }
+        if (traversing) {
+            if (!bvh_step<FAST>(cur, P.scene.bvh, ps.o, ps.d, best, stack, 1)) {
+                traversing = false;
+                have_hit = true;
+            }
         }
     }
     atomicAdd(P.stats, n_seg);
