@@ -10,6 +10,10 @@ constexpr int BLOCK = 256;           // 4 waves of 64
 constexpr uint32_t POOL_BATCH = 64;  // work items a wave takes from the global queue at a time
 constexpr uint32_t NO_ITEM = 0xFFFFFFFFu;
 constexpr int MAX_DEPTH = 1024;      // PT_MAX_DEPTH
+// The hierarchy megakernel runs its shading block when at least NUM/DEN of a wave's live lanes wait
+// for it. Measured on the million-triangle heightfield (800x800, 16 spp): 1/8 14.4 ms, 1/4 13.1 ms,
+// 1/2 13.3 ms, 3/4 15.9 ms.
+constexpr int BVH_REFILL_NUM = 1, BVH_REFILL_DEN = 2;
 constexpr int MAX_LDS_SURFACES = 64 * 1024 / (12 * 4);   // shading records kept in LDS (64 KiB)
 
 // How a kernel sees the scene.  Without a hierarchy every surface is scanned
@@ -396,7 +400,7 @@ k_render_mega_bvh(RenderParams P)
     for (;;) {
         const unsigned long long waiting = __ballot(!traversing);
         const unsigned long long live = __ballot(1);
-        if (2 * __popcll(waiting) >= __popcll(live)) {       // wave-uniform
+        if (BVH_REFILL_DEN * __popcll(waiting) >= BVH_REFILL_NUM * __popcll(live)) {       // wave-uniform
             bool need_path = false;
             if (!traversing) {
                 need_path = !have_hit;
