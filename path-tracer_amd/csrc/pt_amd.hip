@@ -161,8 +161,7 @@ constexpr int BVH_AUTO_MIN_TRIANGLES = 256;
 int build_hierarchy(pt_ctx *ctx, const pt_surface *surfaces, int n_surfaces)
 {
     if (ctx->d_loose) (void)hipFree(ctx->d_loose);
-    if (ctx->d_bvh_nodes) (void)hipFree(ctx->d_bvh_nodes);
-    if (ctx->d_bvh_leaves) (void)hipFree(ctx->d_bvh_leaves);
+    if (ctx->d_bvh_nodes) (void)hipFree(ctx->d_bvh_nodes);      // the leaves live in the same allocation
     ctx->d_loose = nullptr;
     ctx->d_bvh_nodes = nullptr;
     ctx->d_bvh_leaves = nullptr;
@@ -228,8 +227,10 @@ int build_hierarchy(pt_ctx *ctx, const pt_surface *surfaces, int n_surfaces)
     if ((rc = dev_alloc(ctx, &d_parent_node.p, (size_t)n))) return rc;
     if ((rc = dev_alloc(ctx, &d_parent_leaf.p, (size_t)n))) return rc;
     if ((rc = dev_alloc(ctx, &d_arrivals.p, (size_t)n))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->d_bvh_nodes, (size_t)n * BVH_NODE_QUADS))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->d_bvh_leaves, (size_t)n * GEOM_STRIDE))) return rc;
+    // one array of 64-byte records: n for the nodes (n - 1 used), then the n leaves
+    static_assert(BVH_NODE_QUADS * sizeof(float4) == GEOM_STRIDE * sizeof(float), "nodes and leaves share a record size");
+    if ((rc = dev_alloc(ctx, &ctx->d_bvh_nodes, (size_t)2 * n * BVH_NODE_QUADS))) return rc;
+    ctx->d_bvh_leaves = reinterpret_cast<float *>(ctx->d_bvh_nodes + (size_t)n * BVH_NODE_QUADS);
     if ((rc = dev_alloc(ctx, &ctx->d_loose, std::max<size_t>(loose.size(), 1)))) return rc;
     if (!loose.empty())
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_loose, loose.data(), loose.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
@@ -555,8 +556,7 @@ void pt_destroy(pt_ctx *ctx)
     if (ctx->d_geom) (void)hipFree(ctx->d_geom);
     if (ctx->d_shade) (void)hipFree(ctx->d_shade);
     if (ctx->d_loose) (void)hipFree(ctx->d_loose);
-    if (ctx->d_bvh_nodes) (void)hipFree(ctx->d_bvh_nodes);
-    if (ctx->d_bvh_leaves) (void)hipFree(ctx->d_bvh_leaves);
+    if (ctx->d_bvh_nodes) (void)hipFree(ctx->d_bvh_nodes);      // the leaves live in the same allocation
     if (ctx->d_accum) (void)hipFree(ctx->d_accum);
     if (ctx->d_slabs) (void)hipFree(ctx->d_slabs);
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);

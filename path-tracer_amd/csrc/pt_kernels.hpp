@@ -377,14 +377,21 @@ k_render_mega(RenderParams P)
 // The megakernel for scenes with a hierarchy.  A traversal takes tens of
 // dependent steps whose number differs from lane to lane, so lanes are
 // decoupled at the granularity of one traversal step: a lane whose traversal
-// has finished waits until at least half of the wave's live lanes wait too;
-// then they all shade their hits, start their next segments (or paths, or
-// work items) and scan the surfaces outside the hierarchy together, while in
-// every iteration each traversing lane advances by one node or leaf.
+// has finished waits until at least BVH_REFILL_NUM/DEN of the wave's live
+// lanes wait too; then they all shade their hits, start their next segments
+// (or paths, or work items) and scan the surfaces outside the hierarchy
+// together, while in every iteration each traversing lane advances by one node
+// or leaf.  The records of a step are fetched by the wave as a whole
+// (bvh_fetch_records), which needs all 64 lanes: a lane that finds the queue
+// empty stays in the loop, idle, until the whole wave is done.
+// (79 VGPRs: 6 waves per SIMD.  Forced down to 64 VGPRs for 8 waves, the kernel
+// spills and was measured 9 % slower.)
 template <bool FAST>
 __global__ void __launch_bounds__(BLOCK)
 k_render_mega_bvh(RenderParams P)
 {
+    __shared__ __align__(16) char fetch_lds[(BLOCK / 64) * BVH_FETCH_LDS];
+    char *lds_wave = fetch_lds + (threadIdx.x / 64) * BVH_FETCH_LDS;
     const float *shade = P.scene.shade;
     WorkPool pool = {0, 0, false};
     ItemState it = {false, 0, 0, 0, 0, 0, 0, 0, v3(0, 0, 0)};
@@ -393,16 +400,19 @@ k_render_mega_bvh(RenderParams P)
     BvhCursor cur;
     cur.node = 0; cur.sp = 0; cur.inv = v3(0, 0, 0); cur.len_d = 1.0f; cur.inv_len = 1.0f;
     int stack[BVH_STACK];
+    bool alive = true;              // false: the queue is empty and this lane has nothing left
     bool traversing = false;        // false: waiting to shade / start a segment
     bool have_hit = false;          // a finished segment waits to be shaded
     unsigned long long n_seg = 0;
 
     for (;;) {
-        const unsigned long long waiting = __ballot(!traversing);
-        const unsigned long long live = __ballot(1);
-        if (BVH_REFILL_DEN * __popcll(waiting) >= BVH_REFILL_NUM * __popcll(live)) {       // wave-uniform
+        const int n_alive = __popcll(__ballot(alive));
+        if (n_alive == 0) break;                                 // wave-uniform
+        const int n_waiting = __popcll(__ballot(alive && !traversing));
+        if (BVH_REFILL_DEN * n_waiting >= BVH_REFILL_NUM * n_alive) {          // wave-uniform
+            const bool waits = alive && !traversing;
             bool need_path = false;
-            if (!traversing) {
+            if (waits) {
                 need_path = !have_hit;
                 if (have_hit) {
                     if (best.idx < 0) best.dist = 0.0f;
@@ -419,11 +429,11 @@ k_render_mega_bvh(RenderParams P)
                 if (want && it.have) item_close(it, P.slabs);
                 const uint32_t got = pool_take(pool, want, P.queue_head, P.n_items);
                 if (want) {
-                    if (got == NO_ITEM) break;               // queue empty: this lane retires
-                    item_open(it, got, P.cam, P.n_pixels, P.first_sample, P.spp, P.chunk_len, P.seed_mix);
+                    if (got == NO_ITEM) alive = false;       // queue empty: this lane retires
+                    else item_open(it, got, P.cam, P.n_pixels, P.first_sample, P.spp, P.chunk_len, P.seed_mix);
                 }
             }
-            if (!traversing) {
+            if (waits && alive) {
                 if (need_path) path_begin(ps, P.cam, it.pixel_key, it.s, it.px, it.py);
                 // the surfaces outside the hierarchy first, then the hierarchy
                 best = closest_intersection<FAST, true>(as_constant(P.scene.geom), P.scene.n_scan, ps.o, ps.d,
@@ -434,8 +444,11 @@ k_render_mega_bvh(RenderParams P)
                 n_seg++;
             }
         }
+        float4 q0, q1, q2, q3;
+        bvh_fetch_records(P.scene.bvh.nodes, traversing ? bvh_record_of(P.scene.bvh, cur.node) : 0u, lds_wave,
+                          q0, q1, q2, q3);
         if (traversing) {
-            if (!bvh_step<FAST>(cur, P.scene.bvh, ps.o, ps.d, best, stack, 1)) {
+            if (!bvh_advance<FAST>(cur, q0, q1, q2, q3, ps.o, ps.d, best, stack, 1)) {
                 traversing = false;
                 have_hit = true;
             }
