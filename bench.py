@@ -159,7 +159,8 @@ def main():
             "roofline": {"bound": "valu", "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP32_VECTOR_PEAK_TFLOPS,
                          "traffic": pmc_traffic(),
-                         "kernel": "k_render_mega" if args.layout == "megakernel" else "k_wf_bounce (all launches)",
+                         "kernel": ("k_wf_bounce (all launches)" if args.layout != "megakernel" else
+                                    "k_render_mega_bvh" if c.accel == pt_amd.ACCEL_BVH else "k_render_mega"),
                          "kernel_ms": avg_ms,
                          "flops_per_launch": sum(flops) / len(flops)},
             "tests_per_s": sum(segments) / len(segments) * n_surf / (avg_ms * 1e-3),
@@ -168,6 +169,10 @@ def main():
             "vgprs": int(c.vgprs),
             "grid_blocks": int(c.grid_blocks),
         }
+        if c.accel == pt_amd.ACCEL_BVH:
+            # flops and tests count what the reference's scan of every surface would
+            # do for these segments, not what the traversal executed
+            out["roofline"]["effective"] = True
         if world == 1 and args.layout == "megakernel":
             # the other numeric policy on the same workload, for the record (not the headline)
             other = "fast" if args.numeric == "exact" else "exact"

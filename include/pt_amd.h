@@ -91,6 +91,10 @@ typedef struct pt_counters {
     double flops;              /* algorithmic flops: segments x (63 n_tri + 18 n_sph) */
     uint32_t vgprs;            /* registers per lane of the render kernel */
     uint32_t grid_blocks;      /* megakernel: workgroups launched; wavefront: bounce launches */
+    uint32_t accel;            /* PT_ACCEL_BVH if the last pt_render went through a hierarchy (tests and
+                                  flops then count what the reference's scan would do, not what ran),
+                                  else PT_ACCEL_NONE */
+    uint32_t reserved;
 } pt_counters;
 
 typedef struct pt_ctx pt_ctx;

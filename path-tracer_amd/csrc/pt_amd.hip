@@ -367,6 +367,7 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
     ctx->last.samples = (uint64_t)n_pixels * spp;
     ctx->last.vgprs = (uint32_t)attr.numRegs;
     ctx->last.grid_blocks = grid;
+    ctx->last.accel = KIND == SCENE_BVH ? PT_ACCEL_BVH : PT_ACCEL_NONE;
     ctx->last_valid = true;
     ctx->last_pending = true;
     return PT_OK;
@@ -490,6 +491,7 @@ int launch_wavefront(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sam
     ctx->last.samples = (uint64_t)n_pixels * spp;
     ctx->last.vgprs = (uint32_t)attr.numRegs;
     ctx->last.grid_blocks = launches;
+    ctx->last.accel = KIND == SCENE_BVH ? PT_ACCEL_BVH : PT_ACCEL_NONE;
     ctx->last_valid = true;
     ctx->last_pending = true;
     return PT_OK;

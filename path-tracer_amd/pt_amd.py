@@ -43,7 +43,8 @@ class Counters(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("tests", C.c_uint64),
                 ("redone", C.c_uint64),
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("flops", C.c_double),
-                ("vgprs", C.c_uint32), ("grid_blocks", C.c_uint32)]
+                ("vgprs", C.c_uint32), ("grid_blocks", C.c_uint32),
+                ("accel", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class PtError(RuntimeError):
