@@ -1,0 +1,127 @@
+// Exercises the host scene model (scene builders, flattening, scene files,
+// camera matrices) through its C entry points.  Built with AddressSanitizer and
+// UndefinedBehaviorSanitizer by tests/test_host_sanitize.py; needs no GPU.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "pt_amd.h"
+
+extern "C" {
+int pt_host_builtin_scene(const char *, int, int, pt_surface *, pt_material *, int32_t, int32_t *, float[3], pt_camera *);
+int pt_host_load_scene(const char *, int, int, pt_surface *, pt_material *, int32_t, int32_t *, float[3], pt_camera *);
+int pt_host_save_scene(const char *, int, int, const char *);
+const char *pt_host_last_error(void);
+void pt_host_camera_matrix(float, float, int, float[9]);
+}
+
+static int failures = 0;
+#define CHECK(cond) do { if (!(cond)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); failures++; } } while (0)
+
+int main(int argc, char **argv)
+{
+    const std::string tmp = argc > 1 ? argv[1] : "/tmp";
+    const char *names[] = {"cornell", "cornell_2", "orange_plane", "red_corner", "glass_stress", "heightfield:9"};
+    for (const char *name : names) {
+        int32_t n = -1;
+        float bg[3];
+        pt_camera cam;
+        int rc = pt_host_builtin_scene(name, 64, 48, nullptr, nullptr, 0, &n, bg, &cam);
+        CHECK(rc == -2 && n > 0);
+        std::vector<pt_surface> s(n);
+        std::vector<pt_material> m(n);
+        rc = pt_host_builtin_scene(name, 64, 48, s.data(), m.data(), n, &n, bg, &cam);
+        CHECK(rc == 0 && cam.width == 64 && cam.height == 48);
+
+        const std::string path = tmp + "/sanitize_scene.txt";
+        CHECK(pt_host_save_scene(name, 64, 48, path.c_str()) == 0);
+        int32_t n2 = -1;
+        float bg2[3];
+        pt_camera cam2;
+        std::vector<pt_surface> s2(n);
+        std::vector<pt_material> m2(n);
+        rc = pt_host_load_scene(path.c_str(), 64, 48, s2.data(), m2.data(), n, &n2, bg2, &cam2);
+        CHECK(rc == 0 && n2 == n);
+        if (rc == 0 && n2 == n) {
+            CHECK(std::memcmp(s.data(), s2.data(), sizeof(pt_surface) * n) == 0);
+            CHECK(std::memcmp(m.data(), m2.data(), sizeof(pt_material) * n) == 0);
+            CHECK(std::memcmp(&cam, &cam2, sizeof cam) == 0);
+        }
+        // a capacity one short must report the size and write nothing past it
+        if (n > 1) {
+            std::vector<pt_surface> s3(n - 1);
+            std::vector<pt_material> m3(n - 1);
+            CHECK(pt_host_load_scene(path.c_str(), 64, 48, s3.data(), m3.data(), n - 1, &n2, bg2, &cam2) == -2 && n2 == n);
+        }
+    }
+    {
+        int32_t n = 0;
+        float bg[3];
+        pt_camera cam;
+        CHECK(pt_host_builtin_scene("no_such_scene", 8, 8, nullptr, nullptr, 0, &n, bg, &cam) == -1);
+        CHECK(pt_host_builtin_scene("heightfield:0", 8, 8, nullptr, nullptr, 0, &n, bg, &cam) != 0);
+        CHECK(pt_host_builtin_scene("heightfield:-3", 8, 8, nullptr, nullptr, 0, &n, bg, &cam) != 0);
+        CHECK(pt_host_builtin_scene("heightfield:x", 8, 8, nullptr, nullptr, 0, &n, bg, &cam) != 0);
+        CHECK(pt_host_save_scene("cornell", 8, 8, (tmp + "/no/such/dir/x.txt").c_str()) == -3);
+        CHECK(pt_host_load_scene((tmp + "/does_not_exist.txt").c_str(), 8, 8, nullptr, nullptr, 0, &n, bg, &cam) == -3);
+        CHECK(std::strlen(pt_host_last_error()) > 0);
+    }
+    // malformed scene files: every one must be refused with a message, none may crash
+    const char *bad[] = {
+        "",
+        "background 0 0 0\n",
+        "camera 0 0 0 0 0\n",
+        "camera 0 0 0 0 0 fast\n",
+        "camera 0 0 0 0 0 auto\nsphere 0 0 0 1 nobody\n",
+        "camera 0 0 0 0 0 auto\nmaterial a shiny 1 1 1\n",
+        "camera 0 0 0 0 0 auto\nmaterial a diffuse 1 1\n",
+        "camera 0 0 0 0 0 auto\nmaterial a diffuse 1 1 1 2\n",
+        "camera 0 0 0 0 0 auto\nmaterial a diffuse 1 1 1\ntriangle 0 0 0 1 1 1 a\n",
+        "camera 0 0 0 0 0 auto\ndof\n",
+        "camera 0 0 0 0 0 auto\ndof wide 2\n",
+        "camera 0 0 0 0 0 auto\ndof 0.1\n",
+        "camera 0 0 0 0 0 auto\nteapot 1 2 3\n",
+        "camera 0 0 0 0 0 auto\nmaterial a diffuse 1 1 1\nsphere 0 0 0 1e999 a\n",
+    };
+    for (const char *text : bad) {
+        const std::string path = tmp + "/sanitize_bad.txt";
+        { std::ofstream out(path); out << text; }
+        int32_t n = 0;
+        float bg[3];
+        pt_camera cam;
+        pt_surface s[4];
+        pt_material m[4];
+        const int rc = pt_host_load_scene(path.c_str(), 8, 8, s, m, 4, &n, bg, &cam);
+        if (rc != -3) std::printf("accepted: %s", text);
+        CHECK(rc == -3 && std::strlen(pt_host_last_error()) > 0);
+    }
+    // a well-formed file with comments, redefinition of a material, non-finite but parseable values
+    {
+        const std::string path = tmp + "/sanitize_good.txt";
+        { std::ofstream out(path);
+          out << "# comment\ncamera 0 0 -3 0 0 auto   # trailing\nbackground 0.1 0.2 0.3\ndof 0.15 5\n"
+                 "material a diffuse 1 0 0\nmaterial a mirror 1 1 1\nsphere 0 0 0 1 a\n"
+                 "material lamp diffuse 0 0 0 5 5 5\ntriangle 0 0 0 1 0 0 0 1 0 lamp\n\n"; }
+        int32_t n = 0;
+        float bg[3];
+        pt_camera cam;
+        pt_surface s[4];
+        pt_material m[4];
+        CHECK(pt_host_load_scene(path.c_str(), 32, 16, s, m, 4, &n, bg, &cam) == 0);
+        CHECK(n == 2 && m[0].type == 1 && m[1].emittance[0] == 5.0f && cam.dof_on == 1 && cam.focal == 16.0f);
+        CHECK(bg[1] == 0.2f);
+    }
+    for (int off = 0; off < 2; off++) {
+        float rot[9];
+        pt_host_camera_matrix(0.3f, -1.2f, off, rot);
+        float det = rot[0] * (rot[4] * rot[8] - rot[7] * rot[5]) - rot[3] * (rot[1] * rot[8] - rot[7] * rot[2]) +
+                    rot[6] * (rot[1] * rot[5] - rot[4] * rot[2]);
+        CHECK(std::fabs(det - 1.0f) < 1e-5f);
+    }
+    std::printf(failures ? "%d check(s) failed\n" : "host checks passed\n", failures);
+    return failures ? 1 : 0;
+}
