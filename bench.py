@@ -87,15 +87,22 @@ def main():
                          "--nproc-per-node %d" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("no GPU: the render step has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # PT_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs
+    # than ranks (ranks then share devices); the default is RCCL, one GPU per rank.
+    backend = os.environ.get("PT_BENCH_BACKEND", "nccl")
+    device = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
 
     width, height = args.size
     mode = (pt_amd.MODE_WAVEFRONT if args.layout == "wavefront" else pt_amd.MODE_MEGAKERNEL) | \
            (pt_amd.NUM_FAST if args.numeric == "fast" else pt_amd.NUM_EXACT)
     scene = pt_amd.builtin_scene(args.scene, width, height)
-    ctx = pt_amd.Context(local_rank)
+    ctx = pt_amd.Context(device)
     ctx.load(scene)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     accum = torch.zeros(height, width, 3, dtype=torch.float32, device="cuda")
@@ -154,7 +161,8 @@ def main():
                            args.scene, width, height, args.spp, args.layout, args.numeric),
                        "scene": args.scene, "width": width, "height": height, "spp_per_gpu": args.spp,
                        "layout": args.layout, "numeric": args.numeric,
-                       "parallelism": "spp-partition x%d + one RCCL reduce per step" % world
+                       "parallelism": "spp-partition x%d + one %s reduce per step" % (
+                                          world, "RCCL" if backend == "nccl" else backend)
                                       if world > 1 else "single GPU"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP32_VECTOR_PEAK_TFLOPS,

@@ -38,5 +38,14 @@ def reduce_image(accum, dst=0, group=None):
     """Sums the ranks' accumulation buffers onto rank `dst` with one collective."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        if accum.is_cuda and dist.get_backend(group) == "gloo":
+            # gloo has no reduce for device tensors: stage through the host.  Only
+            # rehearsals of the multi-rank path on a box with fewer GPUs than ranks
+            # come here; with RCCL ("nccl") the reduce runs on the device buffers.
+            host = accum.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM, group=group)
+            if dist.get_rank(group) == dst:
+                accum.copy_(host)
+        else:
+            dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return accum

@@ -1,0 +1,57 @@
+"""bench.py end to end on the GPU: the one-line JSON contract at N=1, and the
+multi-rank path (partition by global sample number, barrier, one reduce per
+step, max-over-ranks timing) rehearsed with two ranks that share the one GPU of
+the test box over gloo.  With RCCL the same code runs one rank per GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+SMALL = ["--size", "160", "120", "--spp", "8", "--steps", "2", "--warmup", "1"]
+
+
+def run(cmd, env=None):
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=280,
+                       env=dict(os.environ, **(env or {})))
+    assert p.returncode == 0, (p.stdout + p.stderr)[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def check_contract(out, n_gpus):
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in out, key
+    assert out["n_gpus"] == n_gpus and out["steps"] == 2 and out["warmup"] == 1
+    assert out["unit"] == "Msamples/s" and out["scaling"] == "weak" and out["higher_is_better"] is True
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+    # value = whole-job samples / max-over-ranks time
+    samples = 160 * 120 * 8 * n_gpus
+    assert abs(out["value"] - samples / (out["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * out["value"]
+    r = out["roofline"]
+    assert r["bound"] == "valu" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["kernel_ms"] > 0
+
+
+def test_bench_single_gpu_contract():
+    out = run([sys.executable, "bench.py", "--cpu-spp", "1"] + SMALL)
+    check_contract(out, 1)
+    cpu = out["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0
+    assert out["other_numeric"]["numeric"] == "fast"
+    assert 4.0 < out["segments_per_sample"] < 6.0
+
+
+def test_bench_two_ranks_share_one_gpu_over_gloo():
+    out = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "2"] + SMALL,
+              env={"PT_BENCH_BACKEND": "gloo"})
+    check_contract(out, 2)
+    assert "cpu_baseline" not in out
+    assert "gloo" in out["config"]["parallelism"]
