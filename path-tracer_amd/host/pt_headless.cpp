@@ -5,20 +5,31 @@
 //
 //   pt_headless [-scene NAME | -file SCENE.txt] [-width W] [-height H] [-passes N]
 //               [-batch B] [-fast] [-out FILE.ppm]
+//               [-log] [-exit] [-keys SCRIPT] [-images DIR]
 //
 // -batch B > 0 renders B samples per pixel in one GPU call per pass through
 // pt::Renderer, keeping the sums on the device, instead of one sample per
 // trace_rays call.
+//
+// -log, -exit, -keys or -images select the interactive loop (pt_viewer.hpp)
+// with its window replaced by a replay script: -log saves DIR/<passes>.bmp at
+// 100, 200, 400, ... passes and -exit stops at the first of them, as in the
+// reference (src/main.cpp:275-308); every line of SCRIPT is
+// "<frames> <milliseconds per frame> <keys>", keys like "w+left" or "-" for
+// none, named as in src/main.cpp:178-247.  The loop ends with the script (or
+// after -passes frames without one).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <sstream>
 #include <string>
 
 #include "pt_render.hpp"
 #include "pt_scene_io.hpp"
 #include "pt_scenes.hpp"
+#include "pt_viewer.hpp"
 
 static bool write_ppm(const std::string &path, int width, int height, const std::vector<uint8_t> &rgb)
 {
@@ -34,7 +45,8 @@ int main(int argc, char *argv[])
 {
     std::string scene_name = "orange_plane", scene_file, out;   // the reference's default scene (src/main.cpp:311)
     int width = 356, height = 200, passes = 100, batch = 0;
-    bool fast = false;
+    bool fast = false, viewer = false, log_images = false, exit_at_target = false;
+    std::string key_script, image_dir = "../images/";
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&](const char *what) -> const char * {
@@ -49,6 +61,10 @@ int main(int argc, char *argv[])
         else if (a == "-batch") batch = std::atoi(next("-batch"));
         else if (a == "-out") out = next("-out");
         else if (a == "-fast") fast = true;
+        else if (a == "-log") { viewer = log_images = true; }
+        else if (a == "-exit") { viewer = exit_at_target = true; }
+        else if (a == "-keys") { viewer = true; key_script = next("-keys"); }
+        else if (a == "-images") { viewer = true; image_dir = next("-images"); if (!image_dir.empty() && image_dir.back() != '/') image_dir += '/'; }
         else { std::cerr << "unknown argument " << a << std::endl; return 2; }
     }
     if (width < 1 || height < 1 || passes < 1 || batch < 0) { std::cerr << "bad size" << std::endl; return 2; }
@@ -69,7 +85,49 @@ int main(int argc, char *argv[])
         const auto t0 = std::chrono::steady_clock::now();
         std::vector<uint8_t> rgb;
         double mean[3] = {0, 0, 0};
-        if (batch == 0) {
+        if (viewer) {
+            // frames to replay: (count, dt, keys)
+            struct Span { long frames; float dt; pt::KeyState keys; };
+            std::vector<Span> spans;
+            if (key_script.empty()) {
+                spans.push_back({passes, 16.0f, pt::KeyState{}});
+            } else {
+                std::ifstream in(key_script);
+                if (!in) { std::cerr << "cannot open " << key_script << std::endl; return 2; }
+                std::string line;
+                int line_no = 0;
+                while (std::getline(in, line)) {
+                    line_no++;
+                    const size_t hash = line.find('#');
+                    if (hash != std::string::npos) line.erase(hash);
+                    std::istringstream ss(line);
+                    Span sp{};
+                    std::string keys;
+                    if (!(ss >> sp.frames)) continue;
+                    if (!(ss >> sp.dt >> keys) || sp.frames < 0 || !(sp.dt >= 0) || !pt::KeyState::parse(keys, sp.keys)) {
+                        std::cerr << key_script << " line " << line_no << ": expected <frames> <ms> <keys>" << std::endl;
+                        return 2;
+                    }
+                    spans.push_back(sp);
+                }
+            }
+            pt::Viewer view(*scene, width, height, batch > 0 ? static_cast<uint32_t>(batch) : 1u, 0, image_dir,
+                            PT_MODE_MEGAKERNEL | (fast ? PT_NUM_FAST : PT_NUM_EXACT));
+            view.logging.save_image = log_images;
+            view.logging.exit = exit_at_target;
+            if (exit_at_target) std::cerr << "will exit at " << view.logging.next_target << std::endl;
+            bool go = true;
+            long frames = 0;
+            for (const Span &sp : spans)
+                for (long f = 0; f < sp.frames && go; f++, frames++) go = view.frame(sp.keys, sp.dt);
+            const std::vector<float> sums = view.renderer().read_sums();
+            for (size_t i = 0; i < sums.size(); i += 3) { mean[0] += sums[i]; mean[1] += sums[i + 1]; mean[2] += sums[i + 2]; }
+            if (!out.empty()) rgb = view.renderer().tonemap();
+            const vec3 &p = scene->camera.get_position();
+            const vec2 &r = scene->camera.get_rotation();
+            std::printf("frames=%ld camera_pos=%.9g,%.9g,%.9g camera_rot=%.9g,%.9g dof=%d,%.9g,%.9g\n", frames, p.x, p.y, p.z,
+                        r.x, r.y, scene->DOF_on ? 1 : 0, scene->DOF_aperture_size, scene->DOF_focal_length);
+        } else if (batch == 0) {
             BUFFER buffer(width, std::vector<vec3>(height, vec3()));
             for (int pass = 0; pass < passes; pass++) {
                 scene->camera.update();

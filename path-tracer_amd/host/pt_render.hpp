@@ -48,6 +48,28 @@ struct FlatScene {
     bool same_camera(const FlatScene &o) const { return std::memcmp(&camera, &o.camera, sizeof camera) == 0; }
 };
 
+// The camera and depth-of-field settings of a Scene for a width x height image.
+inline pt_camera flatten_camera(const Scene &scene, int width, int height)
+{
+    pt_camera out{};
+    const Camera &cam = scene.camera;
+    const vec3 &p = cam.get_position();
+    out.pos[0] = p.x; out.pos[1] = p.y; out.pos[2] = p.z;
+    const mat3 &r = cam.get_rotation_matrix();
+    for (int c = 0; c < 3; c++) {
+        out.rot[3 * c + 0] = r[c].x;
+        out.rot[3 * c + 1] = r[c].y;
+        out.rot[3 * c + 2] = r[c].z;
+    }
+    out.focal = cam.get_focal_length();
+    out.width = width;
+    out.height = height;
+    out.dof_on = scene.DOF_on ? 1 : 0;
+    out.dof_focal_length = scene.DOF_focal_length;
+    out.dof_aperture = scene.DOF_aperture_size;
+    return out;
+}
+
 inline FlatScene flatten(const Scene &scene, int width, int height)
 {
     FlatScene f{};
@@ -65,21 +87,7 @@ inline FlatScene flatten(const Scene &scene, int width, int height)
         f.materials.push_back(m);
     }
     f.bg[0] = scene.BG_COLOR.x; f.bg[1] = scene.BG_COLOR.y; f.bg[2] = scene.BG_COLOR.z;
-    const Camera &cam = scene.camera;
-    const vec3 &p = cam.get_position();
-    f.camera.pos[0] = p.x; f.camera.pos[1] = p.y; f.camera.pos[2] = p.z;
-    const mat3 &r = cam.get_rotation_matrix();
-    for (int c = 0; c < 3; c++) {
-        f.camera.rot[3 * c + 0] = r[c].x;
-        f.camera.rot[3 * c + 1] = r[c].y;
-        f.camera.rot[3 * c + 2] = r[c].z;
-    }
-    f.camera.focal = cam.get_focal_length();
-    f.camera.width = width;
-    f.camera.height = height;
-    f.camera.dof_on = scene.DOF_on ? 1 : 0;
-    f.camera.dof_focal_length = scene.DOF_focal_length;
-    f.camera.dof_aperture = scene.DOF_aperture_size;
+    f.camera = flatten_camera(scene, width, height);
     return f;
 }
 
@@ -127,6 +135,19 @@ class Renderer {
         loaded_ = std::move(f);
         have_scene_ = true;
         return cleared;
+    }
+
+    // The same for a scene whose surfaces have not changed since the last sync
+    // (an interactive session moves only the camera): compares and uploads the
+    // camera and depth-of-field settings alone, without flattening the surfaces.
+    bool sync_camera(const Scene &scene, int width, int height)
+    {
+        if (!have_scene_) return sync(scene, width, height);
+        const pt_camera cam = flatten_camera(scene, width, height);
+        if (std::memcmp(&cam, &loaded_.camera, sizeof cam) == 0) return false;
+        check(pt_set_camera(ctx_, &cam));   // clears
+        loaded_.camera = cam;
+        return true;
     }
 
     void clear() { check(pt_clear(ctx_)); }

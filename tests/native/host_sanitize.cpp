@@ -6,10 +6,14 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <iterator>
+#include <sstream>
 #include <string>
 #include <vector>
 
 #include "pt_amd.h"
+#include "pt_scenes.hpp"
+#include "pt_viewer.hpp"
 
 extern "C" {
 int pt_host_builtin_scene(const char *, int, int, pt_surface *, pt_material *, int32_t, int32_t *, float[3], pt_camera *);
@@ -121,6 +125,78 @@ int main(int argc, char **argv)
         float det = rot[0] * (rot[4] * rot[8] - rot[7] * rot[5]) - rot[3] * (rot[1] * rot[8] - rot[7] * rot[2]) +
                     rot[6] * (rot[1] * rot[5] - rot[4] * rot[2]);
         CHECK(std::fabs(det - 1.0f) < 1e-5f);
+    }
+    // the interactive loop's input handling (no window, no GPU)
+    {
+        pt::KeyState keys;
+        CHECK(pt::KeyState::parse("w+left+u", keys) && keys[pt::KEY_W] && keys[pt::KEY_LEFT] && keys[pt::KEY_U] && !keys[pt::KEY_S]);
+        CHECK(pt::KeyState::parse("-", keys) && keys.down.none());
+        CHECK(!pt::KeyState::parse("w+x", keys));
+
+        set_screen_size(64, 48);
+        Scene scene = Scenes::cornell_2();
+        pt::Logging logging;
+        std::ostringstream msg;
+        CHECK(!scene.camera.update());                         // a fresh scene's camera is clean
+        const vec3 p0 = scene.camera.get_position();
+        const vec2 r0 = scene.camera.get_rotation();
+
+        pt::KeyState::parse("-", keys);
+        CHECK(!pt::handle_input(scene, 16.0f, keys, logging, msg) && !scene.camera.update());
+
+        pt::KeyState::parse("q", keys);                        // straight up by dt/1000
+        CHECK(!pt::handle_input(scene, 500.0f, keys, logging, msg));
+        CHECK(scene.camera.update() && !scene.camera.update());
+        CHECK(scene.camera.get_position().y == p0.y + 0.5f && scene.camera.get_position().x == p0.x);
+
+        pt::KeyState::parse("w", keys);                        // forward along the yaw direction
+        pt::handle_input(scene, 1000.0f, keys, logging, msg);
+        CHECK(scene.camera.update());
+        const vec3 p1 = scene.camera.get_position();
+        const double c = std::cos(-double(r0.y)), sn = std::sin(-double(r0.y));
+        CHECK(std::fabs(p1.x - float(p0.x - 1.0 * sn)) < 1e-6f && std::fabs(p1.z - float(p0.z + 1.0 * c)) < 1e-6f);
+
+        pt::KeyState::parse("up+right", keys);
+        pt::handle_input(scene, 250.0f, keys, logging, msg);
+        CHECK(scene.camera.update());
+        CHECK(std::fabs(scene.camera.get_rotation().x - (r0.x + 0.25f)) < 1e-6f);
+        CHECK(std::fabs(scene.camera.get_rotation().y - (r0.y + 0.25f)) < 1e-6f);
+        pt::KeyState::parse("up", keys);                       // pitch is clamped at pi/2
+        for (int i = 0; i < 4; i++) { pt::handle_input(scene, 1000.0f, keys, logging, msg); scene.camera.update(); }
+        CHECK(scene.camera.get_rotation().x == float(M_PI_2));
+        pt::KeyState::parse("left", keys);                     // yaw wraps into [0, 2 pi]
+        for (int i = 0; i < 3; i++) { pt::handle_input(scene, 1000.0f, keys, logging, msg); scene.camera.update(); }
+        CHECK(scene.camera.get_rotation().y >= 0.0f && scene.camera.get_rotation().y <= float(2 * M_PI));
+
+        const bool dof0 = scene.DOF_on;
+        pt::KeyState::parse(dof0 ? "u" : "j", keys);           // a DOF key that changes nothing still restarts the image
+        CHECK(pt::handle_input(scene, 16.0f, keys, logging, msg) && scene.DOF_on == dof0);
+        pt::KeyState::parse("u+i+o", keys);
+        const float f0 = scene.DOF_focal_length, a0 = scene.DOF_aperture_size;
+        CHECK(pt::handle_input(scene, 16.0f, keys, logging, msg) && scene.DOF_on);
+        CHECK(scene.DOF_focal_length == f0 + 0.1f && scene.DOF_aperture_size == a0 + 0.01f);
+        pt::KeyState::parse("j+k+l", keys);
+        CHECK(pt::handle_input(scene, 16.0f, keys, logging, msg) && !scene.DOF_on);
+        CHECK(scene.DOF_focal_length == f0 + 0.1f - 0.1f && scene.DOF_aperture_size == a0 + 0.01f - 0.01f);
+        pt::KeyState::parse("1", keys);
+        CHECK(!pt::handle_input(scene, 16.0f, keys, logging, msg) && logging.save_image);
+        pt::KeyState::parse("2", keys);
+        pt::handle_input(scene, 16.0f, keys, logging, msg);
+        CHECK(!logging.save_image && logging.next_target == 100 && !logging.exit);
+        CHECK(msg.str().find("depth of field enabled") != std::string::npos);
+    }
+    // the BMP writer: 3 x 2 pixels, rows padded to 12 bytes, bottom row first, B G R
+    {
+        const std::vector<uint8_t> rgb = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18};
+        const std::string path = tmp + "/sanitize.bmp";
+        CHECK(pt::write_bmp(path, 3, 2, rgb));
+        std::ifstream in(path, std::ios::binary);
+        std::vector<unsigned char> b((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+        CHECK(b.size() == 54 + 24 && b[0] == 'B' && b[1] == 'M' && b[2] == 78 && b[10] == 54 && b[14] == 40);
+        CHECK(b[18] == 3 && b[22] == 2 && b[26] == 1 && b[28] == 24);
+        CHECK(b[54] == 12 && b[55] == 11 && b[56] == 10 && b[54 + 9] == 0 && b[54 + 12] == 3 && b[54 + 13] == 2);
+        CHECK(!pt::write_bmp(path, 3, 2, std::vector<uint8_t>(5)));
+        CHECK(!pt::write_bmp(tmp + "/no/such/dir/x.bmp", 3, 2, rgb));
     }
     std::printf(failures ? "%d check(s) failed\n" : "host checks passed\n", failures);
     return failures ? 1 : 0;
