@@ -1,0 +1,35 @@
+"""Times the closest-hit search over the million-triangle height field with the
+linear scan and with the hierarchy, on a full-size launch (800x800 camera rays).
+   python tools/brute_vs_bvh.py [quads]
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd"))
+import torch  # noqa: E402  (first: its HIP runtime must initialise before the library's)
+torch.cuda.init()
+import numpy as np  # noqa: E402
+import pt_amd  # noqa: E402
+
+quads = int(sys.argv[1]) if len(sys.argv) > 1 else 707
+scene = pt_amd.builtin_scene("heightfield:%d" % quads, 800, 800)
+n = len(scene.surfaces)
+ctx = pt_amd.Context(0)
+out = {}
+for name, accel in (("hierarchy", pt_amd.ACCEL_BVH), ("scan", pt_amd.ACCEL_NONE)):
+    ctx.set_accel(accel)
+    ctx.load(scene)
+    ctx.primary_hits()                       # warm-up
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        idx, dist = ctx.primary_hits()
+        best = min(best, time.perf_counter() - t0)
+    out[name] = (best, idx, dist)
+    print("%-10s %d surfaces, 640000 rays: %.3f ms  (%.3g ray-surface pairs/s)" % (name, n, best * 1e3, 640000 * n / best),
+          flush=True)
+same = np.array_equal(out["scan"][1], out["hierarchy"][1]) and np.array_equal(out["scan"][2], out["hierarchy"][2])
+print("identical results:", same)
+sys.exit(0 if same else 1)
