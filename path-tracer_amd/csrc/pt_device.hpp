@@ -396,7 +396,7 @@ PT_DEV Hit closest_intersection(cfloat_p geom, int n_surfaces, V3 o, V3 d,
             const float inv = __builtin_amdgcn_rcpf(q.det_a);
             const float u = q.du * inv, v = q.dv * inv, t = q.dt * inv;
             const float s = u + v;
-            const bool det_bad = q.det_a >= -EPS_F && q.det_a <= EPS_F;
+            const bool det_bad = __builtin_fabsf(q.det_a) <= EPS_F;      // false for a NaN, as in the reference
             const float dist = t * len_d;
             // non-short-circuit on purpose: every comparison is one instruction
             if constexpr (FAST) {
@@ -404,10 +404,11 @@ PT_DEV Hit closest_intersection(cfloat_p geom, int n_surfaces, V3 o, V3 d,
                 rej = !acc;
                 c_lo = c_hi = dist;
             } else {
-                rej = det_bad | (u < BAND_LO_REJ) | (u > BAND_ONE_REJ) | (v < BAND_LO_REJ) |
-                      (s > BAND_ONE_REJ) | (t < BAND_T_REJ);
-                acc = !det_bad & (u > BAND_LO_ACC) & (u < BAND_ONE_ACC) & (v > BAND_LO_ACC) &
-                      (s < BAND_ONE_ACC) & (t > BAND_T_ACC);
+                // min/max drop a NaN operand; a NaN in u or v still fails s < BAND_ONE_ACC,
+                // so it can make neither acc nor (alone) rej true and the lane is redone
+                const float low_uv = __builtin_fminf(u, v);
+                rej = det_bad | (low_uv < BAND_LO_REJ) | (__builtin_fmaxf(u, s) > BAND_ONE_REJ) | (t < BAND_T_REJ);
+                acc = !det_bad & (low_uv > BAND_LO_ACC) & (u < BAND_ONE_ACC) & (s < BAND_ONE_ACC) & (t > BAND_T_ACC);
                 c_lo = dist * (1.0f - TRI_DIST_ERR);
                 c_hi = dist * (1.0f + TRI_DIST_ERR);
             }
@@ -440,13 +441,11 @@ PT_DEV Hit closest_intersection(cfloat_p geom, int n_surfaces, V3 o, V3 d,
             a = tca;
             b = arg;
         }
+        // src/main.cpp:61: a later surface replaces the current one only when strictly closer;
         // a candidate that is not a hit never wins and never ties
-        c_lo = acc ? c_lo : INF;
-        c_hi = acc ? c_hi : INF;
-        // src/main.cpp:61: a later surface replaces the current one only when strictly closer
-        const bool closer = c_hi < best.lo;
+        const bool closer = acc & (c_hi < best.lo);
         if constexpr (!FAST) {
-            const bool not_closer = c_lo >= best.hi;
+            const bool not_closer = !acc | (c_lo >= best.hi);
             unsure = unsure | !(acc | rej) | !(closer | not_closer);
         }
         if (closer) best = {4 * i + mode, c_lo, c_hi, a, b};
