@@ -314,6 +314,13 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
     int blocks_per_cu = 0;
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, BLOCK, lds_bytes));
     if (blocks_per_cu < 1) return fail(ctx, PT_E_HIP, "render kernel does not fit on a compute unit");
+    // A small launch ends when its longest path does, and one loop iteration takes
+    // about as long with two waves on a SIMD as with eight: fewer, busier waves
+    // finish such a launch sooner.  Measured against launching all that fit:
+    // 356x200 at 1 spp 244 -> 124 us (one workgroup per CU), 800x800 at 4 spp
+    // 698 -> 609 us (three); from about 64 spp at 800x800 all that fit is fastest.
+    const double samples = (double)n_pixels * spp;
+    blocks_per_cu = std::min(blocks_per_cu, std::max(1, (int)std::lround(std::sqrt(samples / 3e5))));
     const uint32_t grid = (uint32_t)blocks_per_cu * (uint32_t)ctx->num_cus;
     const uint64_t lanes = (uint64_t)grid * BLOCK;
 
