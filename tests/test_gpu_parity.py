@@ -547,3 +547,40 @@ def test_hierarchy_on_the_million_triangle_scene(ctx, pt):
         assert c.segments > 2 * c.samples
     finally:
         ctx.set_accel(pt.ACCEL_AUTO)
+
+
+def test_hierarchy_render_is_bit_identical_to_the_scan_render(ctx, pt):
+    """The same paths through the hierarchy megakernel and through the scan megakernel: every
+    closest hit is the same, so are the random streams and the order of additions per work
+    item, hence the images are equal bit for bit (both numeric policies are exact about which
+    triangle a leaf test accepts only in EXACT; FAST is compared loosely)."""
+    sc = pt.builtin_scene("heightfield:40", 160, 120)        # 3200 small triangles + walls + spheres
+    images = {}
+    try:
+        for accel in (pt.ACCEL_NONE, pt.ACCEL_BVH):
+            ctx.set_accel(accel)
+            load(ctx, sc)
+            for mode in (pt.MODE_MEGAKERNEL | pt.NUM_EXACT, pt.MODE_WAVEFRONT | pt.NUM_EXACT,
+                         pt.MODE_MEGAKERNEL | pt.NUM_FAST):
+                ctx.clear()
+                ctx.render(24, 5, 7, mode)
+                acc, total = ctx.read_accum()
+                c = ctx.counters()
+                assert total == 24 and c.accel == accel
+                images[(accel, mode)] = (acc, c.segments)
+    finally:
+        ctx.set_accel(pt.ACCEL_AUTO)
+    exact = pt.MODE_MEGAKERNEL | pt.NUM_EXACT
+    ref, seg = images[(pt.ACCEL_NONE, exact)]
+    assert ref.sum() > 0 and seg > 3 * 160 * 120 * 24
+    got, gseg = images[(pt.ACCEL_BVH, exact)]
+    assert gseg == seg and np.array_equal(got, ref)
+    # the wavefront layout adds a pixel's samples in the same order too
+    for accel in (pt.ACCEL_NONE, pt.ACCEL_BVH):
+        wf, wseg = images[(accel, pt.MODE_WAVEFRONT | pt.NUM_EXACT)]
+        assert wseg == seg
+        assert np.allclose(wf, ref, rtol=1e-5, atol=1e-5)
+    fast_scan, _ = images[(pt.ACCEL_NONE, pt.MODE_MEGAKERNEL | pt.NUM_FAST)]
+    fast_bvh, _ = images[(pt.ACCEL_BVH, pt.MODE_MEGAKERNEL | pt.NUM_FAST)]
+    assert abs(fast_bvh.mean() - fast_scan.mean()) < 0.02 * fast_scan.mean()
+    assert abs(fast_scan.mean() - ref.mean()) < 0.02 * ref.mean()
