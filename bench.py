@@ -62,14 +62,15 @@ def cpu_baseline(scene_name, width, height, spp):
                 scene_name, width, height, spp, dt, cnt.segments / cnt.samples)}
 
 
-def pmc_traffic():
-    """HBM bytes per render-kernel launch from the committed rocprofv3 PMC summary, if any."""
+def pmc_summary():
+    """The committed rocprofv3 PMC summary of the headline launch (tools/profile_gpu.sh +
+    tools/make_profile_summary.py --traffic), or {} if there is none."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
+            return json.load(f)
     except (OSError, ValueError):
-        return None
+        return {}
 
 
 def main():
@@ -144,6 +145,10 @@ def main():
         avg_ms = sum(kernel_ms) / len(kernel_ms)
         achieved = sum(flops) / len(flops) / (avg_ms * 1e-3) / 1e12
         n_surf = len(scene.surfaces)
+        # counters belong to the headline launch only
+        headline = (args.scene == "cornell_2" and (width, height, args.spp) == (800, 800, 1024) and
+                    args.layout == "megakernel" and args.numeric == "exact")
+        pmc = pmc_summary() if headline else {}
         out = {
             "metric": "Msamples/sec, 800x800 Cornell box (diffuse+mirror+glass)",
             "value": value,
@@ -166,7 +171,7 @@ def main():
                                       if world > 1 else "single GPU"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP32_VECTOR_PEAK_TFLOPS,
-                         "traffic": pmc_traffic(),
+                         "traffic": pmc.get("hbm_bytes_per_launch"),
                          "kernel": ("k_wf_bounce (all launches)" if args.layout != "megakernel" else
                                     "k_render_mega_bvh" if c.accel == pt_amd.ACCEL_BVH else "k_render_mega"),
                          "kernel_ms": avg_ms,
@@ -177,6 +182,13 @@ def main():
             "vgprs": int(c.vgprs),
             "grid_blocks": int(c.grid_blocks),
         }
+        if "valu_insts_per_simd_cycle" in pmc:
+            # the other reading of the same roofline: how busy the vector pipe is, whatever
+            # the instructions compute (a SIMD issues at most one VALU instruction per two cycles)
+            out["roofline"]["valu_issue"] = {"insts_per_simd_cycle": pmc["valu_insts_per_simd_cycle"],
+                                             "peak": 0.5,
+                                             "frac": pmc["valu_insts_per_simd_cycle"] / 0.5,
+                                             "lane_utilisation": pmc.get("valu_lane_utilisation")}
         if c.accel == pt_amd.ACCEL_BVH:
             # flops and tests count what the reference's scan of every surface would
             # do for these segments, not what the traversal executed

@@ -57,9 +57,14 @@ if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
     if avg_ns:
         lines.append("  over the kernel's %.3f ms: %.2f GB/s of 8000 GB/s" % (avg_ns / 1e6, hbm / avg_ns))
     if "--traffic" in sys.argv:
+        rec = {"hbm_bytes_per_launch": hbm, "fetch_size_kib": mean["FETCH_SIZE"],
+               "write_size_kib": mean["WRITE_SIZE"], "kernel": kern, "source": tag + ".txt"}
+        if "SQ_INSTS_VALU" in mean and "GRBM_GUI_ACTIVE" in mean:
+            rec["valu_insts_per_simd_cycle"] = mean["SQ_INSTS_VALU"] / (1024 * mean["GRBM_GUI_ACTIVE"] / 8)
+        if "SQ_THREAD_CYCLES_VALU" in mean and "SQ_ACTIVE_INST_VALU" in mean:
+            rec["valu_lane_utilisation"] = mean["SQ_THREAD_CYCLES_VALU"] / (64 * mean["SQ_ACTIVE_INST_VALU"])
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
-            json.dump({"hbm_bytes_per_launch": hbm, "fetch_size_kib": mean["FETCH_SIZE"],
-                       "write_size_kib": mean["WRITE_SIZE"], "kernel": kern, "source": tag + ".txt"}, f)
+            json.dump(rec, f)
 if "SQ_INSTS_VALU" in mean and "SQ_THREAD_CYCLES_VALU" in mean and "SQ_ACTIVE_INST_VALU" in mean:
     lines.append("VALU lane utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) = %.3f" % (
         mean["SQ_THREAD_CYCLES_VALU"] / (64 * mean["SQ_ACTIVE_INST_VALU"])))
