@@ -20,7 +20,13 @@ ctx = pt_amd.Context(0)
 out = {}
 for name, accel in (("hierarchy", pt_amd.ACCEL_BVH), ("scan", pt_amd.ACCEL_NONE)):
     ctx.set_accel(accel)
+    t0 = time.perf_counter()
     ctx.load(scene)
+    t1 = time.perf_counter()
+    ctx.load(scene)
+    t2 = time.perf_counter()
+    print("%-10s pt_set_scene + pt_set_camera: first %.1f ms, again %.1f ms" % (name, (t1 - t0) * 1e3, (t2 - t1) * 1e3),
+          flush=True)
     ctx.primary_hits()                       # warm-up
     best = 1e9
     for _ in range(3):
