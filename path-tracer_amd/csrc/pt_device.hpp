@@ -251,6 +251,28 @@ PT_DEV TriDets triangle_dets(cfloat_p g, V3 o, V3 nd)
     return triangle_dets_v<FAST>(v3(g[0], g[1], g[2]), v3(g[4], g[5], g[6]), g[7], v3(g[8], g[9], g[10]), o, nd);
 }
 
+// Floats 0..11 of a geometry record, read with a wave-uniform index in one go
+// (scalar loads of 8 + 4 dwords, one wait), whichever kind the surface has.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+struct GeomRec { f32x4 q0, q1, q2; int kind; };
+
+PT_DEV GeomRec geom_load(cfloat_p g)
+{
+    typedef const __attribute__((address_space(4))) f32x4 *cf32x4_p;
+    typedef const __attribute__((address_space(4))) i32x4 *ci32x4_p;
+    const cf32x4_p p = (cf32x4_p)g;
+    // The kind is read as an integer lane of an integer vector: a bit cast of one
+    // float lane of the loaded vector makes this compiler narrow the load to a
+    // single dword at the vector's base (the lane offset is lost).
+    const i32x4 first = ((ci32x4_p)g)[0];
+    GeomRec r;
+    r.kind = first.w;
+    r.q0 = __builtin_bit_cast(f32x4, first);
+    r.q1 = p[1]; r.q2 = p[2];
+    return r;
+}
+
 // Triangle::intersects, src/surface.hpp:47-73, evaluated directly: IEEE
 // quotients in EXACT.  Returns true on a hit; t, distance = length(t*ray_dir).
 template <bool FAST>
@@ -275,11 +297,9 @@ PT_DEV bool triangle_direct(cfloat_p g, V3 o, V3 d, V3 nd, float &t_out, float &
 // root: tca, and arg = radius2 - d2.  pre_ok is false when the reference has
 // already returned (tca < 0 or d2 > radius2).
 template <bool FAST>
-PT_DEV bool sphere_pre(cfloat_p g, V3 o, V3 d, float &tca, float &arg)
+PT_DEV bool sphere_pre_v(V3 c, float radius2, V3 o, V3 d, float &tca, float &arg)
 {
     using N = Num<FAST>;
-    const V3 c = v3(g[0], g[1], g[2]);
-    const float radius2 = g[4];
     const V3 L = c - o;
     tca = N::dot(L, d);
     bool ok = !(tca < 0.0f);                                        // :94
@@ -289,6 +309,12 @@ PT_DEV bool sphere_pre(cfloat_p g, V3 o, V3 d, float &tca, float &arg)
     ok = ok && !(d2 > radius2);                                     // :98
     arg = radius2 - d2;
     return ok;
+}
+
+template <bool FAST>
+PT_DEV bool sphere_pre(cfloat_p g, V3 o, V3 d, float &tca, float &arg)
+{
+    return sphere_pre_v<FAST>(v3(g[0], g[1], g[2]), g[4], o, d, tca, arg);
 }
 
 // Sphere::intersects, src/surface.hpp:91-112, evaluated directly.
@@ -386,13 +412,14 @@ PT_DEV Hit closest_intersection(cfloat_p geom, int n_surfaces, V3 o, V3 d,
     for (int j = 0; j < n_surfaces; j++) {
         // index_map (ascending scene indices) restricts the scan to a subset of the scene
         const int i = index_map ? index_map[j] : j;
-        cfloat_p g = geom + (size_t)i * GEOM_STRIDE;
+        const GeomRec rec = geom_load(geom + (size_t)i * GEOM_STRIDE);
         bool acc;           // surely a hit (FAST: a hit)
         bool rej;           // surely not a hit
         int mode;
         float c_lo, c_hi, a, b;
-        if (__builtin_bit_cast(int, g[3]) == 0) {    // wave-uniform branch
-            const TriDets q = triangle_dets<FAST>(g, o, nd);
+        if (rec.kind == 0) {                         // wave-uniform branch
+            const TriDets q = triangle_dets_v<FAST>(v3(rec.q0.x, rec.q0.y, rec.q0.z), v3(rec.q1.x, rec.q1.y, rec.q1.z),
+                                                    rec.q1.w, v3(rec.q2.x, rec.q2.y, rec.q2.z), o, nd);
             const float inv = __builtin_amdgcn_rcpf(q.det_a);
             const float u = q.du * inv, v = q.dv * inv, t = q.dt * inv;
             const float s = u + v;
@@ -417,7 +444,7 @@ PT_DEV Hit closest_intersection(cfloat_p geom, int n_surfaces, V3 o, V3 d,
             b = q.det_a;
         } else {
             float tca, arg;
-            const bool pre_ok = sphere_pre<FAST>(g, o, d, tca, arg);
+            const bool pre_ok = sphere_pre_v<FAST>(v3(rec.q0.x, rec.q0.y, rec.q0.z), rec.q1.x, o, d, tca, arg);
             const float thc = __builtin_amdgcn_sqrtf(arg);
             const float t1 = tca - thc, t2 = tca + thc;
             if constexpr (FAST) {
