@@ -62,6 +62,27 @@ def cpu_baseline(scene_name, width, height, spp):
                 scene_name, width, height, spp, dt, cnt.segments / cnt.samples)}
 
 
+def intersection_kernel(pt_amd, scene_name, device):
+    """The closest-hit search on its own: k_primary_hits over the camera rays of a 4096x4096
+    image of the same scene (16.8 M rays, one segment each), priced like the render kernel."""
+    side = 4096
+    ctx = pt_amd.Context(device)
+    ctx.load(pt_amd.builtin_scene(scene_name, side, side))
+    out = {"kernel": "k_primary_hits", "rays": side * side}
+    for name, numeric in (("exact", pt_amd.NUM_EXACT), ("fast", pt_amd.NUM_FAST)):
+        best = None
+        for _ in range(3):
+            ctx.primary_hits(numeric)
+            c = ctx.counters()
+            if best is None or c.kernel_ms < best.kernel_ms:
+                best = c
+        tf = best.flops / (best.kernel_ms * 1e-3) / 1e12
+        out[name] = {"kernel_ms": best.kernel_ms, "tests_per_s": best.tests / (best.kernel_ms * 1e-3),
+                     "achieved": tf, "unit": "TFLOP/s", "frac": tf / FP32_VECTOR_PEAK_TFLOPS, "vgprs": int(best.vgprs)}
+    ctx.close()
+    return out
+
+
 def pmc_summary():
     """The committed rocprofv3 PMC summary of the headline launch (tools/profile_gpu.sh +
     tools/make_profile_summary.py --traffic), or {} if there is none."""
@@ -206,6 +227,8 @@ def main():
             out["other_numeric"] = {"numeric": other, "kernel_ms": min(ms),
                                     "value": width * height * args.spp / (min(ms) * 1e-3) / 1e6,
                                     "roofline_frac": oc.flops / (min(ms) * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS}
+        if world == 1:
+            out["intersection_kernel"] = intersection_kernel(pt_amd, args.scene, device)
         if world == 1 and args.cpu_spp > 0:
             out["cpu_baseline"] = cpu_baseline(args.scene, width, height, args.cpu_spp)
         print(json.dumps(out), flush=True)

@@ -81,6 +81,8 @@ typedef struct pt_camera {
     float dof_aperture;
 } pt_camera;
 
+/* Counters of the last pt_render, or of the last closest-hit query
+ * (pt_primary_hits, pt_intersect_rays: one segment per ray, redone = 0). */
 typedef struct pt_counters {
     uint64_t samples;          /* paths traced by the last pt_render */
     uint64_t segments;         /* closest-hit queries (src/main.cpp:85) in the last pt_render */

@@ -778,6 +778,31 @@ int pt_tonemap_rgb8(pt_ctx *ctx, uint8_t *out_host)
     return PT_OK;
 }
 
+namespace {
+// Counters of a closest-hit query (pt_primary_hits, pt_intersect_rays): one segment per ray.
+// Call after the stream has been synchronised; ev[0] and ev[1] bracket the kernel.
+int note_query(pt_ctx *ctx, long long n_rays, const void *kernel, unsigned grid, int kind)
+{
+    float ms = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    hipFuncAttributes attr{};
+    HIP_TRY(ctx, hipFuncGetAttributes(&attr, kernel));
+    ctx->last = pt_counters{};
+    ctx->last.samples = (uint64_t)n_rays;
+    ctx->last.segments = (uint64_t)n_rays;
+    ctx->last.tests = (uint64_t)n_rays * (uint64_t)ctx->n_surfaces;
+    ctx->last.kernel_ms = ms;
+    ctx->last.total_ms = ms;
+    ctx->last.flops = (double)n_rays * (63.0 * ctx->n_tri + 18.0 * ctx->n_sph);
+    ctx->last.vgprs = (uint32_t)attr.numRegs;
+    ctx->last.grid_blocks = grid;
+    ctx->last.accel = kind == SCENE_BVH ? PT_ACCEL_BVH : PT_ACCEL_NONE;
+    ctx->last_valid = true;
+    ctx->last_pending = false;
+    return PT_OK;
+}
+}  // namespace
+
 int pt_primary_hits(pt_ctx *ctx, int32_t *surf_idx, float *distance, int numeric)
 {
     int rc = check_ready(ctx, true);
@@ -788,16 +813,20 @@ int pt_primary_hits(pt_ctx *ctx, int32_t *surf_idx, float *distance, int numeric
     Scratch<float> d_dist;
     if ((rc = dev_alloc(ctx, &d_idx.p, (size_t)n))) return rc;
     if ((rc = dev_alloc(ctx, &d_dist.p, (size_t)n))) return rc;
+    const void *kernel = nullptr;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     rc = with_variant((numeric & PT_NUM_FAST) != 0, scene_kind(ctx), [&]<bool FAST, int KIND>() {
+        kernel = reinterpret_cast<const void *>(&k_primary_hits<FAST, KIND>);
         hipLaunchKernelGGL((k_primary_hits<FAST, KIND>), dim3(blocks_for(n)), dim3(BLOCK), lds_bytes_for(ctx, KIND), ctx->stream,
                            ctx->cam, scene_view(ctx), d_idx.p, d_dist.p);
         return PT_OK;
     });
     HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(surf_idx, d_idx.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(distance, d_dist.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return PT_OK;
+    return note_query(ctx, n, kernel, blocks_for(n), scene_kind(ctx));
 }
 
 int pt_intersect_rays(pt_ctx *ctx, const float *origin, const float *dir, int64_t n,
@@ -815,17 +844,21 @@ int pt_intersect_rays(pt_ctx *ctx, const float *origin, const float *dir, int64_
     if ((rc = dev_alloc(ctx, &d_idx.p, (size_t)n))) return rc;
     if ((rc = dev_alloc(ctx, &d_dist.p, (size_t)n))) return rc;
     if ((rc = dev_alloc(ctx, &d_pt.p, (size_t)n * 3))) return rc;
+    const void *kernel = nullptr;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     rc = with_variant((numeric & PT_NUM_FAST) != 0, scene_kind(ctx), [&]<bool FAST, int KIND>() {
+        kernel = reinterpret_cast<const void *>(&k_intersect_rays<FAST, KIND>);
         hipLaunchKernelGGL((k_intersect_rays<FAST, KIND>), dim3(blocks_for(n)), dim3(BLOCK), lds_bytes_for(ctx, KIND), ctx->stream,
                            scene_view(ctx), d_o.p, d_d.p, (long long)n, d_idx.p, d_dist.p, d_pt.p);
         return PT_OK;
     });
     HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(surf_idx, d_idx.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(distance, d_dist.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(point, d_pt.p, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return PT_OK;
+    return note_query(ctx, n, kernel, blocks_for(n), scene_kind(ctx));
 }
 
 int pt_camera_rays(pt_ctx *ctx, const int32_t *px, const float *xi, int64_t n,
