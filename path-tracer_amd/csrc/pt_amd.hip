@@ -324,9 +324,10 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
     const uint32_t grid = (uint32_t)blocks_per_cu * (uint32_t)ctx->num_cus;
     const uint64_t lanes = (uint64_t)grid * BLOCK;
 
-    // Work items: enough per lane (about 16) that the last ones to finish cost
-    // little, but no more chunks than samples.
-    uint64_t want_chunks = (16 * lanes + n_pixels - 1) / n_pixels;
+    // Work items: enough per lane (about 32) that the last ones to finish cost
+    // little, but no more chunks than samples.  (Headline launch: 8 per lane 47.3 ms,
+    // 16: 44.6, 32: 44.0, 64: 43.8 with twice the partial sums again.)
+    uint64_t want_chunks = (32 * lanes + n_pixels - 1) / n_pixels;
     uint32_t n_chunks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want_chunks, 1), spp);
     const uint32_t chunk_len = (spp + n_chunks - 1) / n_chunks;
     n_chunks = (spp + chunk_len - 1) / chunk_len;
