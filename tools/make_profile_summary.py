@@ -15,24 +15,37 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def newest(pattern):
+    """One file per pass directory: gpurun merges every run's output into the same local
+    directories, so an earlier run's files may still lie beside the latest one's."""
+    by_dir = {}
+    for f in glob.glob(pattern):
+        d = os.path.dirname(os.path.dirname(f))
+        if d not in by_dir or os.path.getmtime(f) > os.path.getmtime(by_dir[d]):
+            by_dir[d] = f
+    return sorted(by_dir.values())
+
+
 src, tag = sys.argv[1], sys.argv[2]
 rest = [a for a in sys.argv[3:] if not a.startswith("--")]
 kern = rest[0] if rest else "render_mega"
 lines = ["rocprofv3 summary '%s' (tools/profile_gpu.sh: python3 bench.py --steps 2 --warmup 1 ...)" % tag, ""]
 
 lines.append("== kernel-trace --stats (all kernels) ==")
-for f in sorted(glob.glob(src + "/stats/*/*_kernel_stats.csv")):
+for f in newest(src + "/stats/*/*_kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
         lines.append("%-70s calls=%-5s avg_ns=%-14s min_ns=%-12s max_ns=%-12s pct=%s" % (
             r["Name"][:70], r["Calls"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["Percentage"]))
 avg_ns = None
-for f in sorted(glob.glob(src + "/stats/*/*_kernel_stats.csv")):
+for f in newest(src + "/stats/*/*_kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
         if kern in r["Name"]:
             avg_ns = float(r["AverageNs"])
 lines.append("")
 lines.append("== dispatch of *%s* ==" % kern)
-for f in sorted(glob.glob(src + "/stats/*/*_kernel_trace.csv")):
+for f in newest(src + "/stats/*/*_kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
         if kern in r["Kernel_Name"]:
             lines.append("VGPR_Count=%s Accum_VGPR_Count=%s SGPR_Count=%s LDS_Block_Size=%s Scratch_Size=%s "
@@ -41,7 +54,7 @@ for f in sorted(glob.glob(src + "/stats/*/*_kernel_trace.csv")):
                                                    r["Grid_Size_X"]))
             break
 agg = collections.defaultdict(list)
-for f in sorted(glob.glob(src + "/pmc_*/*/*_counter_collection.csv")):
+for f in newest(src + "/pmc_*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         if kern in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
