@@ -1,6 +1,6 @@
 // C ABI of the MI355X-native render step (declared in include/pt_amd.h):
 // context, scene flattening, launches.  Build with
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
+//   hipcc --offload-arch=gfx950 -O3 -std=c++20 -ffp-contract=off -fno-slp-vectorize -fPIC -shared
 #include "../../include/pt_amd.h"
 #include "pt_kernels.hpp"
 
@@ -14,6 +14,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -505,7 +507,27 @@ int launch_wavefront(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sam
     return PT_OK;
 }
 
+// No exception crosses the C boundary: a failed host allocation becomes PT_E_NOMEM.
+template <class F>
+int guarded(pt_ctx *ctx, F &&f)
+{
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, PT_E_NOMEM, "out of host memory");
+    } catch (const std::exception &e) {
+        return fail(ctx, PT_E_INVALID, "unexpected failure: %s", e.what());
+    }
+}
+
+int render_dispatch_body(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample, uint64_t seed, int mode);
+
 int render_dispatch(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample, uint64_t seed, int mode)
+{
+    return guarded(ctx, [&] { return render_dispatch_body(ctx, accum, spp, first_sample, seed, mode); });
+}
+
+int render_dispatch_body(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample, uint64_t seed, int mode)
 {
     if (spp == 0) return fail(ctx, PT_E_INVALID, "spp must be positive");
     if ((uint64_t)first_sample + spp > 0xFFFFFFFFull)
@@ -587,8 +609,17 @@ int pt_set_stream(pt_ctx *ctx, void *hip_stream)
     return PT_OK;
 }
 
+static int set_scene_body(pt_ctx *ctx, const pt_surface *surfaces, int32_t n_surfaces,
+                          const pt_material *materials, int32_t n_materials, const float bg[3]);
+
 int pt_set_scene(pt_ctx *ctx, const pt_surface *surfaces, int32_t n_surfaces,
                  const pt_material *materials, int32_t n_materials, const float bg[3])
+{
+    return guarded(ctx, [&] { return set_scene_body(ctx, surfaces, n_surfaces, materials, n_materials, bg); });
+}
+
+static int set_scene_body(pt_ctx *ctx, const pt_surface *surfaces, int32_t n_surfaces,
+                          const pt_material *materials, int32_t n_materials, const float bg[3])
 {
     if (!ctx) return fail(nullptr, PT_E_INVALID, "null context");
     if (n_surfaces < 0 || n_materials < 0 || (n_surfaces > 0 && (!surfaces || !materials)) || !bg)
@@ -665,7 +696,7 @@ int pt_set_accel(pt_ctx *ctx, int accel)
     ctx->accel = accel;
     if (!ctx->have_scene) return PT_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return build_hierarchy(ctx, ctx->host_surfaces.data(), ctx->n_surfaces);
+    return guarded(ctx, [&] { return build_hierarchy(ctx, ctx->host_surfaces.data(), ctx->n_surfaces); });
 }
 
 int pt_set_camera(pt_ctx *ctx, const pt_camera *cam)
