@@ -43,14 +43,17 @@ extern "C" {
 #define PT_NUM_EXACT       0x0   /* no FMA contraction, IEEE divide/sqrt: the parity arithmetic */
 #define PT_NUM_FAST        0x10  /* FMA + hardware rcp/rsq/sin/cos */
 
-/* One Surface, in scene order (Scene::surfaces, src/scene.hpp:18).
- * Triangle (src/surface.hpp:33-35): a,b,c = v0,v1,v2.
- * Sphere   (src/surface.hpp:78-79): a = position, b[0] = radius. */
 /* pt_set_accel modes */
 #define PT_ACCEL_AUTO 0   /* hierarchy when the scene has 256 triangles or more */
 #define PT_ACCEL_NONE 1   /* always the reference's linear scan over every surface */
 #define PT_ACCEL_BVH  2   /* hierarchy whenever the scene has two small triangles or more */
+#define PT_ACCEL_LDS_TILES 3  /* linear scan; pt_primary_hits and pt_intersect_rays stage the records
+                                 through LDS in tiles shared by a workgroup (a layout kept for
+                                 comparison), pt_render scans as with PT_ACCEL_NONE */
 
+/* One Surface, in scene order (Scene::surfaces, src/scene.hpp:18).
+ * Triangle (src/surface.hpp:33-35): a,b,c = v0,v1,v2.
+ * Sphere   (src/surface.hpp:78-79): a = position, b[0] = radius. */
 typedef struct pt_surface {
     int32_t kind;        /* PT_TRIANGLE | PT_SPHERE */
     int32_t material;    /* index into the material table */

@@ -168,7 +168,7 @@ int build_hierarchy(pt_ctx *ctx, const pt_surface *surfaces, int n_surfaces)
     ctx->d_bvh_nodes = nullptr;
     ctx->d_bvh_leaves = nullptr;
     ctx->n_bvh = ctx->n_loose = 0;
-    if (ctx->accel == PT_ACCEL_NONE) return PT_OK;
+    if (ctx->accel == PT_ACCEL_NONE || ctx->accel == PT_ACCEL_LDS_TILES) return PT_OK;
     if (ctx->accel == PT_ACCEL_AUTO && ctx->n_tri < BVH_AUTO_MIN_TRIANGLES) return PT_OK;
 
     // bounds of the triangle centroids; a triangle much larger than that spread stays outside
@@ -689,7 +689,7 @@ static int set_scene_body(pt_ctx *ctx, const pt_surface *surfaces, int32_t n_sur
 int pt_set_accel(pt_ctx *ctx, int accel)
 {
     if (!ctx) return fail(nullptr, PT_E_INVALID, "null context");
-    if (accel != PT_ACCEL_AUTO && accel != PT_ACCEL_NONE && accel != PT_ACCEL_BVH)
+    if (accel != PT_ACCEL_AUTO && accel != PT_ACCEL_NONE && accel != PT_ACCEL_BVH && accel != PT_ACCEL_LDS_TILES)
         return fail(ctx, PT_E_INVALID, "unknown acceleration mode %d", accel);
     int rc = use_device(ctx);
     if (rc) return rc;
@@ -848,6 +848,12 @@ int pt_primary_hits(pt_ctx *ctx, int32_t *surf_idx, float *distance, int numeric
     const void *kernel = nullptr;
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     rc = with_variant((numeric & PT_NUM_FAST) != 0, scene_kind(ctx), [&]<bool FAST, int KIND>() {
+        if (ctx->accel == PT_ACCEL_LDS_TILES) {
+            kernel = reinterpret_cast<const void *>(&k_primary_hits_tiled<FAST>);
+            hipLaunchKernelGGL(k_primary_hits_tiled<FAST>, dim3(blocks_for(n)), dim3(BLOCK), 0, ctx->stream,
+                               ctx->cam, scene_view(ctx), d_idx.p, d_dist.p);
+            return PT_OK;
+        }
         kernel = reinterpret_cast<const void *>(&k_primary_hits<FAST, KIND>);
         hipLaunchKernelGGL((k_primary_hits<FAST, KIND>), dim3(blocks_for(n)), dim3(BLOCK), lds_bytes_for(ctx, KIND), ctx->stream,
                            ctx->cam, scene_view(ctx), d_idx.p, d_dist.p);
@@ -879,6 +885,12 @@ int pt_intersect_rays(pt_ctx *ctx, const float *origin, const float *dir, int64_
     const void *kernel = nullptr;
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     rc = with_variant((numeric & PT_NUM_FAST) != 0, scene_kind(ctx), [&]<bool FAST, int KIND>() {
+        if (ctx->accel == PT_ACCEL_LDS_TILES) {
+            kernel = reinterpret_cast<const void *>(&k_intersect_rays_tiled<FAST>);
+            hipLaunchKernelGGL(k_intersect_rays_tiled<FAST>, dim3(blocks_for(n)), dim3(BLOCK), 0, ctx->stream,
+                               scene_view(ctx), d_o.p, d_d.p, (long long)n, d_idx.p, d_dist.p, d_pt.p);
+            return PT_OK;
+        }
         kernel = reinterpret_cast<const void *>(&k_intersect_rays<FAST, KIND>);
         hipLaunchKernelGGL((k_intersect_rays<FAST, KIND>), dim3(blocks_for(n)), dim3(BLOCK), lds_bytes_for(ctx, KIND), ctx->stream,
                            scene_view(ctx), d_o.p, d_d.p, (long long)n, d_idx.p, d_dist.p, d_pt.p);

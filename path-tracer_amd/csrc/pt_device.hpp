@@ -399,85 +399,100 @@ constexpr float TRI_DIST_ERR = 2e-6f, SPH_DIST_ERR = 4e-7f;
 // sphere, t = a + sqrt(b).  code < 0: no hit yet.
 struct Best { int code; float lo, hi, a, b; };
 
+// A closest-hit scan in progress: the best candidate so far and whether any
+// decision taken for this lane fell inside an error band.
+struct Scan { Best best; bool unsure; V3 nd; float len_d; };
+
+template <bool FAST>
+PT_DEV void scan_begin(Scan &st, V3 d)
+{
+    const float INF = __builtin_inff();
+    st.best = {-4, INF, INF, 0.0f, 0.0f};
+    st.unsure = false;
+    st.nd = -d;
+    st.len_d = __builtin_amdgcn_sqrtf(Num<FAST>::dot(d, d));
+}
+
+// One surface against the ray: i = its index in scene order.  Surfaces must
+// be offered in ascending scene order (src/main.cpp:61 keeps the earlier one of
+// two equally distant hits).
+template <bool FAST>
+PT_DEV void scan_surface(Scan &st, int i, const GeomRec &rec, V3 o, V3 d)
+{
+    Best &best = st.best;
+    const float len_d = st.len_d;
+    bool acc;           // surely a hit (FAST: a hit)
+    bool rej;           // surely not a hit
+    int mode;
+    float c_lo, c_hi, a, b;
+    if (rec.kind == 0) {                         // wave-uniform branch
+        const TriDets q = triangle_dets_v<FAST>(v3(rec.q0.x, rec.q0.y, rec.q0.z), v3(rec.q1.x, rec.q1.y, rec.q1.z),
+                                                rec.q1.w, v3(rec.q2.x, rec.q2.y, rec.q2.z), o, st.nd);
+        const float inv = __builtin_amdgcn_rcpf(q.det_a);
+        const float u = q.du * inv, v = q.dv * inv, t = q.dt * inv;
+        const float s = u + v;
+        const bool det_bad = __builtin_fabsf(q.det_a) <= EPS_F;      // false for a NaN, as in the reference
+        const float dist = t * len_d;
+        // non-short-circuit on purpose: every comparison is one instruction
+        if constexpr (FAST) {
+            acc = !(det_bad | (u < -EPS_F) | (u >= 1.0f) | (v < -EPS_F) | (s >= 1.0f) | (t <= EPS_F));
+            rej = !acc;
+            c_lo = c_hi = dist;
+        } else {
+            // min/max drop a NaN operand; a NaN in u or v still fails s < BAND_ONE_ACC,
+            // so it can make neither acc nor (alone) rej true and the lane is redone
+            const float low_uv = __builtin_fminf(u, v);
+            rej = det_bad | (low_uv < BAND_LO_REJ) | (__builtin_fmaxf(u, s) > BAND_ONE_REJ) | (t < BAND_T_REJ);
+            acc = !det_bad & (low_uv > BAND_LO_ACC) & (u < BAND_ONE_ACC) & (s < BAND_ONE_ACC) & (t > BAND_T_ACC);
+            c_lo = dist * (1.0f - TRI_DIST_ERR);
+            c_hi = dist * (1.0f + TRI_DIST_ERR);
+        }
+        mode = 0;
+        a = q.dt;
+        b = q.det_a;
+    } else {
+        float tca, arg;
+        const bool pre_ok = sphere_pre_v<FAST>(v3(rec.q0.x, rec.q0.y, rec.q0.z), rec.q1.x, o, d, tca, arg);
+        const float thc = __builtin_amdgcn_sqrtf(arg);
+        const float t1 = tca - thc, t2 = tca + thc;
+        if constexpr (FAST) {
+            const bool near = !(t1 <= EPS_F);
+            c_lo = c_hi = near ? t1 : t2;
+            acc = pre_ok & !(c_lo <= EPS_F);
+            rej = !acc;
+            mode = near ? 1 : 2;
+        } else {
+            const float e1 = SPH_DIST_ERR * (thc + __builtin_fabsf(t1));
+            const float e2 = SPH_DIST_ERR * (thc + __builtin_fabsf(t2));
+            const float lo1 = t1 - e1, hi1 = t1 + e1, lo2 = t2 - e2, hi2 = t2 + e2;
+            const bool near_ok = lo1 > BAND_T_ACC, near_bad = hi1 < BAND_T_REJ;
+            const bool far_ok = lo2 > BAND_T_ACC, far_bad = hi2 < BAND_T_REJ;
+            acc = pre_ok & (near_ok | (near_bad & far_ok));
+            rej = !pre_ok | (near_bad & far_bad);
+            c_lo = near_ok ? lo1 : lo2;
+            c_hi = near_ok ? hi1 : hi2;
+            mode = near_ok ? 1 : 2;
+        }
+        a = tca;
+        b = arg;
+    }
+    // src/main.cpp:61: a later surface replaces the current one only when strictly closer;
+    // a candidate that is not a hit never wins and never ties
+    const bool closer = acc & (c_hi < best.lo);
+    if constexpr (!FAST) {
+        const bool not_closer = !acc | (c_lo >= best.hi);
+        st.unsure = st.unsure | !(acc | rej) | !(closer | not_closer);
+    }
+    if (closer) best = {4 * i + mode, c_lo, c_hi, a, b};
+}
+
+// The hit a finished scan found, with the reference's t (and distance).  Not
+// for a lane whose scan is unsure: that lane is evaluated by closest_direct.
 template <bool FAST, bool NEED_DIST>
-PT_DEV Hit closest_intersection(cfloat_p geom, int n_surfaces, V3 o, V3 d,
-                                unsigned long long *redo_count = nullptr, const int *index_map = nullptr)
+PT_DEV Hit scan_finish(const Scan &st, V3 d)
 {
     using N = Num<FAST>;
-    const float INF = __builtin_inff();
-    Best best = {-4, INF, INF, 0.0f, 0.0f};
-    bool unsure = false;
-    const V3 nd = -d;
-    const float len_d = __builtin_amdgcn_sqrtf(N::dot(d, d));
-    for (int j = 0; j < n_surfaces; j++) {
-        // index_map (ascending scene indices) restricts the scan to a subset of the scene
-        const int i = index_map ? index_map[j] : j;
-        const GeomRec rec = geom_load(geom + (size_t)i * GEOM_STRIDE);
-        bool acc;           // surely a hit (FAST: a hit)
-        bool rej;           // surely not a hit
-        int mode;
-        float c_lo, c_hi, a, b;
-        if (rec.kind == 0) {                         // wave-uniform branch
-            const TriDets q = triangle_dets_v<FAST>(v3(rec.q0.x, rec.q0.y, rec.q0.z), v3(rec.q1.x, rec.q1.y, rec.q1.z),
-                                                    rec.q1.w, v3(rec.q2.x, rec.q2.y, rec.q2.z), o, nd);
-            const float inv = __builtin_amdgcn_rcpf(q.det_a);
-            const float u = q.du * inv, v = q.dv * inv, t = q.dt * inv;
-            const float s = u + v;
-            const bool det_bad = __builtin_fabsf(q.det_a) <= EPS_F;      // false for a NaN, as in the reference
-            const float dist = t * len_d;
-            // non-short-circuit on purpose: every comparison is one instruction
-            if constexpr (FAST) {
-                acc = !(det_bad | (u < -EPS_F) | (u >= 1.0f) | (v < -EPS_F) | (s >= 1.0f) | (t <= EPS_F));
-                rej = !acc;
-                c_lo = c_hi = dist;
-            } else {
-                // min/max drop a NaN operand; a NaN in u or v still fails s < BAND_ONE_ACC,
-                // so it can make neither acc nor (alone) rej true and the lane is redone
-                const float low_uv = __builtin_fminf(u, v);
-                rej = det_bad | (low_uv < BAND_LO_REJ) | (__builtin_fmaxf(u, s) > BAND_ONE_REJ) | (t < BAND_T_REJ);
-                acc = !det_bad & (low_uv > BAND_LO_ACC) & (u < BAND_ONE_ACC) & (s < BAND_ONE_ACC) & (t > BAND_T_ACC);
-                c_lo = dist * (1.0f - TRI_DIST_ERR);
-                c_hi = dist * (1.0f + TRI_DIST_ERR);
-            }
-            mode = 0;
-            a = q.dt;
-            b = q.det_a;
-        } else {
-            float tca, arg;
-            const bool pre_ok = sphere_pre_v<FAST>(v3(rec.q0.x, rec.q0.y, rec.q0.z), rec.q1.x, o, d, tca, arg);
-            const float thc = __builtin_amdgcn_sqrtf(arg);
-            const float t1 = tca - thc, t2 = tca + thc;
-            if constexpr (FAST) {
-                const bool near = !(t1 <= EPS_F);
-                c_lo = c_hi = near ? t1 : t2;
-                acc = pre_ok & !(c_lo <= EPS_F);
-                rej = !acc;
-                mode = near ? 1 : 2;
-            } else {
-                const float e1 = SPH_DIST_ERR * (thc + __builtin_fabsf(t1));
-                const float e2 = SPH_DIST_ERR * (thc + __builtin_fabsf(t2));
-                const float lo1 = t1 - e1, hi1 = t1 + e1, lo2 = t2 - e2, hi2 = t2 + e2;
-                const bool near_ok = lo1 > BAND_T_ACC, near_bad = hi1 < BAND_T_REJ;
-                const bool far_ok = lo2 > BAND_T_ACC, far_bad = hi2 < BAND_T_REJ;
-                acc = pre_ok & (near_ok | (near_bad & far_ok));
-                rej = !pre_ok | (near_bad & far_bad);
-                c_lo = near_ok ? lo1 : lo2;
-                c_hi = near_ok ? hi1 : hi2;
-                mode = near_ok ? 1 : 2;
-            }
-            a = tca;
-            b = arg;
-        }
-        // src/main.cpp:61: a later surface replaces the current one only when strictly closer;
-        // a candidate that is not a hit never wins and never ties
-        const bool closer = acc & (c_hi < best.lo);
-        if constexpr (!FAST) {
-            const bool not_closer = !acc | (c_lo >= best.hi);
-            unsure = unsure | !(acc | rej) | !(closer | not_closer);
-        }
-        if (closer) best = {4 * i + mode, c_lo, c_hi, a, b};
-    }
-
+    const Best &best = st.best;
     Hit h;
     h.idx = best.code >> 2;
     h.t = 0.0f;
@@ -486,29 +501,42 @@ PT_DEV Hit closest_intersection(cfloat_p geom, int n_surfaces, V3 o, V3 d,
     if constexpr (FAST) {
         h.t = mode == 0 ? best.a * __builtin_amdgcn_rcpf(best.b) : best.lo;
         h.dist = best.lo;
-        return h;
-    } else {
-        if (__any(unsure)) {                         // rare: redo those lanes directly
-            if (unsure) {
+    } else if (h.idx >= 0) {
+        if (mode == 0) {
+            h.t = best.a / best.b;                              // surface.hpp:65
+            if constexpr (NEED_DIST) {
+                const V3 td = d * h.t;                          // surface.hpp:70
+                h.dist = __builtin_sqrtf(N::dot(td, td));
+            }
+        } else {
+            const float thc = __builtin_sqrtf(best.b);          // surface.hpp:101
+            h.t = mode == 1 ? best.a - thc : best.a + thc;
+            h.dist = h.t;                                       // surface.hpp:111
+        }
+    }
+    return h;
+}
+
+template <bool FAST, bool NEED_DIST>
+PT_DEV Hit closest_intersection(cfloat_p geom, int n_surfaces, V3 o, V3 d,
+                                unsigned long long *redo_count = nullptr, const int *index_map = nullptr)
+{
+    Scan st;
+    scan_begin<FAST>(st, d);
+    for (int j = 0; j < n_surfaces; j++) {
+        // index_map (ascending scene indices) restricts the scan to a subset of the scene
+        const int i = index_map ? index_map[j] : j;
+        scan_surface<FAST>(st, i, geom_load(geom + (size_t)i * GEOM_STRIDE), o, d);
+    }
+    if constexpr (!FAST) {
+        if (__any(st.unsure)) {                      // rare: redo those lanes directly
+            if (st.unsure) {
                 if (redo_count) atomicAdd(redo_count, 1ull);
                 return closest_direct<false>(geom, n_surfaces, o, d, index_map);
             }
         }
-        if (h.idx >= 0) {
-            if (mode == 0) {
-                h.t = best.a / best.b;                              // surface.hpp:65
-                if constexpr (NEED_DIST) {
-                    const V3 td = d * h.t;                          // surface.hpp:70
-                    h.dist = __builtin_sqrtf(N::dot(td, td));
-                }
-            } else {
-                const float thc = __builtin_sqrtf(best.b);          // surface.hpp:101
-                h.t = mode == 1 ? best.a - thc : best.a + thc;
-                h.dist = h.t;                                       // surface.hpp:111
-            }
-        }
-        return h;
     }
+    return scan_finish<FAST, NEED_DIST>(st, d);
 }
 
 // ---------------------------------------------------------------- materials

@@ -107,6 +107,99 @@ k_intersect_rays(SceneView scene, const float *org, const float *dir,
     point[3 * i] = pt.x; point[3 * i + 1] = pt.y; point[3 * i + 2] = pt.z;
 }
 
+// ---- the linear scan with records staged through LDS ---------------------------
+//
+// The workgroup copies the geometry records into LDS in tiles of SCAN_TILE,
+// two buffers (tile k + 1 arrives by LDS-DMA while tile k is scanned), and every
+// lane scans the tile with broadcast LDS reads.  This is the textbook layout
+// for a brute-force scan; it exists here to be measured against the scan through
+// the scalar cache (closest_intersection), which needs no LDS, no barriers and no
+// vector registers for the records.  Closest-hit queries only.
+constexpr int SCAN_TILE = 256;                                   // records per tile: 16 KiB
+constexpr int SCAN_TILE_FLOATS = SCAN_TILE * GEOM_STRIDE;
+
+// Every thread of the workgroup must call this, with the same scene (o, d: its own ray).
+template <bool FAST>
+PT_DEV Hit closest_hit_tiled(const SceneView &sc, V3 o, V3 d, float *tiles /* 2 * SCAN_TILE_FLOATS */)
+{
+    typedef const __attribute__((address_space(1))) void *global_p;
+    typedef __attribute__((address_space(3))) void *lds_p;
+    const int n = sc.n_surfaces;
+    const int n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    const int wave_first = (int)(threadIdx.x & ~63u);            // first thread of this wave
+    // One instruction copies 16 bytes per lane: BLOCK lanes move BLOCK / 4 records.
+    constexpr int COPIES = SCAN_TILE * (GEOM_STRIDE / 4) / BLOCK;
+    auto request = [&](int k) {
+        float *dst = tiles + (k & 1) * SCAN_TILE_FLOATS;
+        const float *src = sc.geom + (size_t)k * SCAN_TILE_FLOATS;
+#pragma unroll
+        for (int m = 0; m < COPIES; m++) {
+            const int quad = m * BLOCK + (int)threadIdx.x;                     // 16-byte piece of the tile
+            if ((size_t)k * SCAN_TILE + quad / 4 < (size_t)n)             // no read beyond the last record
+                __builtin_amdgcn_global_load_lds((global_p)(uintptr_t)(src + quad * 4),
+                                                 (lds_p)(uintptr_t)(dst + (m * BLOCK + wave_first) * 4), 16, 0, 0);
+        }
+    };
+
+    Scan st;
+    scan_begin<FAST>(st, d);
+    if (n_tiles > 0) request(0);
+    for (int k = 0; k < n_tiles; k++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this thread's pieces of tile k have landed
+        __syncthreads();                                        // everyone's have, and tile k - 1 is no longer read
+        if (k + 1 < n_tiles) request(k + 1);
+        const float *tile = tiles + (k & 1) * SCAN_TILE_FLOATS;
+        const int count = n - k * SCAN_TILE < SCAN_TILE ? n - k * SCAN_TILE : SCAN_TILE;
+        for (int j = 0; j < count; j++) {
+            const f32x4 *p = reinterpret_cast<const f32x4 *>(tile + j * GEOM_STRIDE);
+            GeomRec rec;
+            rec.q0 = p[0]; rec.q1 = p[1]; rec.q2 = p[2];
+            rec.kind = __builtin_bit_cast(int, tile[j * GEOM_STRIDE + 3]);
+            scan_surface<FAST>(st, k * SCAN_TILE + j, rec, o, d);
+        }
+    }
+    if constexpr (!FAST) {
+        if (st.unsure) return closest_direct<false>(as_constant(sc.geom), n, o, d);
+    }
+    return scan_finish<FAST, true>(st, d);
+}
+
+template <bool FAST>
+__global__ void __launch_bounds__(BLOCK)
+k_primary_hits_tiled(Camera cam, SceneView scene, int32_t *idx, float *dist)
+{
+    __shared__ __align__(16) float tiles[2 * SCAN_TILE_FLOATS];
+    const int p = blockIdx.x * BLOCK + threadIdx.x;
+    const bool live = p < cam.width * cam.height;
+    const int x = live ? p % cam.width : 0, y = live ? p / cam.width : 0;
+    const V3 o = v3(cam.pos[0], cam.pos[1], cam.pos[2]);
+    const V3 d = ray_direction_by_pixel<FAST>(cam, (float)x, (float)y);
+    const Hit h = closest_hit_tiled<FAST>(scene, o, d, tiles);
+    if (!live) return;
+    idx[p] = h.idx;
+    dist[p] = h.idx < 0 ? 0.0f : h.dist;
+}
+
+template <bool FAST>
+__global__ void __launch_bounds__(BLOCK)
+k_intersect_rays_tiled(SceneView scene, const float *org, const float *dir,
+                       long long n, int32_t *idx, float *dist, float *point)
+{
+    __shared__ __align__(16) float tiles[2 * SCAN_TILE_FLOATS];
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    const bool live = i < n;
+    const long long r = live ? i : 0;                           // idle threads still help with the tiles
+    const V3 o = v3(org[3 * r], org[3 * r + 1], org[3 * r + 2]);
+    const V3 d = v3(dir[3 * r], dir[3 * r + 1], dir[3 * r + 2]);
+    const Hit h = closest_hit_tiled<FAST>(scene, o, d, tiles);
+    if (!live) return;
+    idx[i] = h.idx;
+    dist[i] = h.idx < 0 ? 0.0f : h.dist;
+    V3 pt = v3(0, 0, 0);
+    if (h.idx >= 0) pt = Num<FAST>::along(o, d, h.t);
+    point[3 * i] = pt.x; point[3 * i + 1] = pt.y; point[3 * i + 2] = pt.z;
+}
+
 template <bool FAST>
 __global__ void __launch_bounds__(BLOCK)
 k_camera_rays(Camera cam, const int32_t *px, const float *xi, long long n, float *org, float *dir)

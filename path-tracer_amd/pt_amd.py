@@ -25,7 +25,7 @@ TRIANGLE, SPHERE = 0, 1
 MODE_MEGAKERNEL, MODE_WAVEFRONT = 0x0, 0x1
 NUM_EXACT, NUM_FAST = 0x0, 0x10
 MAX_DEPTH = 1024
-ACCEL_AUTO, ACCEL_NONE, ACCEL_BVH = 0, 1, 2
+ACCEL_AUTO, ACCEL_NONE, ACCEL_BVH, ACCEL_LDS_TILES = 0, 1, 2, 3
 
 SCENE_NAMES = ("dof_demo", "test", "orange_plane", "red_corner", "sunrise",
                "cornell_2", "cornell")

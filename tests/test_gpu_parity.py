@@ -584,3 +584,55 @@ def test_hierarchy_render_is_bit_identical_to_the_scan_render(ctx, pt):
     fast_bvh, _ = images[(pt.ACCEL_BVH, pt.MODE_MEGAKERNEL | pt.NUM_FAST)]
     assert abs(fast_bvh.mean() - fast_scan.mean()) < 0.02 * fast_scan.mean()
     assert abs(fast_scan.mean() - ref.mean()) < 0.02 * ref.mean()
+
+
+def test_lds_tiled_scan_equals_the_scan(ctx, pt, orc):
+    """PT_ACCEL_LDS_TILES: the closest-hit queries stage the records through LDS; the results
+    are the reference's, bit for bit, for scenes below, at and above the tile size."""
+    rng = np.random.default_rng(77)
+    try:
+        ctx.set_accel(pt.ACCEL_LDS_TILES)
+        for name, w, h in (("cornell_2", 100, 70), ("glass_stress", 64, 64), ("heightfield:11", 64, 48),
+                           ("heightfield:40", 96, 64)):
+            sc = pt.builtin_scene(name, w, h)
+            osc = as_oracle_scene(orc, sc)
+            load(ctx, sc)
+            idx, dist = ctx.primary_hits()
+            oidx, odist = orc.primary_hits(osc)
+            assert np.array_equal(idx, oidx) and np.array_equal(dist, odist), name
+            assert ctx.counters().accel == pt.ACCEL_NONE       # no hierarchy was used
+            o, d = random_rays(rng, 1000 + 37)                  # not a multiple of the workgroup size
+            got = ctx.intersect_rays(o, d)
+            want = orc.intersect_rays(osc, o, d)
+            for g, w_ in zip(got, want):
+                assert np.array_equal(g, w_), name
+            fi, fd = ctx.primary_hits(pt.NUM_FAST)
+            assert (fi != oidx).mean() < 0.01
+        # exactly one tile, and one record more
+        for n in (256, 257):
+            surf = np.zeros(n, dtype=pt.SURFACE)
+            base = rng.uniform(-2, 2, (n, 3))
+            surf["a"] = base
+            surf["b"] = base + [0.6, 0, 0.1]
+            surf["c"] = base + [0, 0.6, 0.1]
+            mats = np.zeros(1, dtype=pt.MATERIAL)
+            osc = orc.Scene(surf.view(orc.SURFACE), mats.view(orc.MATERIAL), [0, 0, 0],
+                            orc.camera_init([0, 0, 0], 0, 0, 8, 0, 8, 8))
+            ctx.set_scene(surf, mats, [0, 0, 0])
+            o, d = random_rays(rng, 5000, 3.0)
+            got = ctx.intersect_rays(o, d)
+            want = orc.intersect_rays(osc, o, d)
+            for g, w_ in zip(got, want):
+                assert np.array_equal(g, w_), n
+            assert (want[0] == n - 1).any() or n == 256 or (want[0] >= 0).sum() > 100
+        # rendering with this mode set scans as usual
+        load(ctx, pt.builtin_scene("cornell_2", 48, 32))
+        ctx.render(4, 0, 1, 0)
+        a1, _ = ctx.read_accum()
+        ctx.set_accel(pt.ACCEL_NONE)
+        load(ctx, pt.builtin_scene("cornell_2", 48, 32))
+        ctx.render(4, 0, 1, 0)
+        a2, _ = ctx.read_accum()
+        assert np.array_equal(a1, a2)
+    finally:
+        ctx.set_accel(pt.ACCEL_AUTO)
