@@ -162,9 +162,11 @@ int pt_render_into(pt_ctx *ctx, float *accum_device, uint32_t spp, uint32_t firs
 int pt_read_accum(pt_ctx *ctx, float *rgb_sum_host, uint64_t *total_samples);
 
 /* Replaces the accumulation buffer and the sample counter with caller data
- * (height*width*3 floats, row-major): resumes an image read back earlier with
- * pt_read_accum, or hands a host-side BUFFER to pt_tonemap_rgb8. */
-int pt_write_accum(pt_ctx *ctx, const float *rgb_sum_host, uint64_t total_samples);
+ * (height*width*3 floats, row-major, in host or device memory): resumes an
+ * image read back earlier with pt_read_accum, hands a host-side BUFFER to
+ * pt_tonemap_rgb8, or adopts the sum of several GPUs' images (a device buffer
+ * after the reduce) together with their total sample count. */
+int pt_write_accum(pt_ctx *ctx, const float *rgb_sum, uint64_t total_samples);
 
 /* draw()'s per-pixel conversion (src/main.cpp:146-162) with PutPixelSDL's
  * truncation (src/sdl_helpers.hpp:68-70): rgb8 = uint8(to_ldr(sum/N)).

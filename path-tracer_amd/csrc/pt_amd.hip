@@ -779,15 +779,16 @@ int pt_read_accum(pt_ctx *ctx, float *rgb_sum_host, uint64_t *total_samples)
     return PT_OK;
 }
 
-int pt_write_accum(pt_ctx *ctx, const float *rgb_sum_host, uint64_t total_samples)
+int pt_write_accum(pt_ctx *ctx, const float *rgb_sum, uint64_t total_samples)
 {
     if (!ctx) return fail(nullptr, PT_E_INVALID, "null context");
     if (!ctx->have_camera) return fail(ctx, PT_E_INVALID, "pt_set_camera has not been called");
-    if (!rgb_sum_host) return fail(ctx, PT_E_INVALID, "rgb_sum_host is null");
+    if (!rgb_sum) return fail(ctx, PT_E_INVALID, "rgb_sum is null");
     int rc = use_device(ctx);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_accum, rgb_sum_host, ctx->accum_floats * sizeof(float),
-                                hipMemcpyHostToDevice, ctx->stream));
+    // host or device memory: the runtime tells them apart
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_accum, rgb_sum, ctx->accum_floats * sizeof(float),
+                                hipMemcpyDefault, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->total_samples = total_samples;
     return PT_OK;

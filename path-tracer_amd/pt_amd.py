@@ -252,6 +252,10 @@ class Context:
             raise ValueError("sums must hold height*width*3 floats")
         self._check(self._lib.pt_write_accum(self._h, _p(sums), C.c_uint64(total_samples)))
 
+    def write_accum_device(self, device_ptr, total_samples):
+        """The same from a device buffer of height*width*3 floats (e.g. the reduced image of several GPUs)."""
+        self._check(self._lib.pt_write_accum(self._h, C.c_void_p(device_ptr), C.c_uint64(total_samples)))
+
     def tonemap_rgb8(self):
         out = np.empty((self.height, self.width, 3), dtype=np.uint8)
         self._check(self._lib.pt_tonemap_rgb8(self._h, _p(out)))

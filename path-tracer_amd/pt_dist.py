@@ -49,3 +49,10 @@ def reduce_image(accum, dst=0, group=None):
         else:
             dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return accum
+
+
+def adopt_image(renderer, accum, total_spp):
+    """On the destination rank after reduce_image: makes the combined image (and the sample
+    count of all ranks together) the renderer's own, so that its tone map and read-back see it.
+    `renderer` offers write_accum_device(device_ptr, total_samples), as pt_amd.Context does."""
+    renderer.write_accum_device(accum.data_ptr(), total_spp)

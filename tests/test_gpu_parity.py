@@ -636,3 +636,29 @@ def test_lds_tiled_scan_equals_the_scan(ctx, pt, orc):
         assert np.array_equal(a1, a2)
     finally:
         ctx.set_accel(pt.ACCEL_AUTO)
+
+
+def test_combined_device_image_can_be_adopted_and_tone_mapped(ctx, pt):
+    """What rank 0 does after the reduce of a multi-GPU render: the sum of the ranks' device
+    buffers (here two sample ranges rendered into torch tensors) becomes the context's image,
+    with the total sample count, and tone-maps like the one-range render."""
+    import torch
+    import pt_dist
+    sc = pt.builtin_scene("orange_plane", 96, 54)
+    load(ctx, sc)
+    ctx.render(16, 0, 9, 0)
+    want_rgb = ctx.tonemap_rgb8()
+    want, _ = ctx.read_accum()
+    shares = []
+    for rank in range(2):
+        t = torch.zeros(54, 96, 3, dtype=torch.float32, device="cuda")
+        assert pt_dist.render_share(ctx, t, 16, 2, rank, first_sample=0, seed=9) == 8
+        shares.append(t)
+    total = shares[0] + shares[1]
+    torch.cuda.synchronize()
+    ctx.clear()
+    pt_dist.adopt_image(ctx, total, 16)
+    got, n = ctx.read_accum()
+    assert n == 16 and np.allclose(got, want, rtol=1e-5, atol=1e-5)
+    rgb = ctx.tonemap_rgb8()
+    assert np.abs(rgb.astype(int) - want_rgb.astype(int)).max() <= 1

@@ -39,6 +39,9 @@ class OracleRenderer:
         acc = t.numpy()
         self.orc.render(self.scene, spp, first_sample=first_sample, seed=seed, threads=2, accum=acc)
 
+    def write_accum_device(self, ptr, total_samples):
+        self.adopted = (self.tensors[ptr].numpy().copy(), total_samples)
+
 
 def _worker(rank, world, port, out_path):
     import torch
@@ -57,6 +60,9 @@ def _worker(rank, world, port, out_path):
     assert n == (4 if rank == 0 else 5)
     pt_dist.reduce_image(accum, dst=0)
     if rank == 0:
+        pt_dist.adopt_image(r, accum, 9)
+        image, total = r.adopted
+        assert total == 9 and np.array_equal(image, accum.numpy())
         np.save(out_path, accum.numpy())
     dist.barrier()
     dist.destroy_process_group()
