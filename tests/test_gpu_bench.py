@@ -49,8 +49,12 @@ def test_bench_single_gpu_contract():
 
 
 def test_bench_two_ranks_share_one_gpu_over_gloo():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
     out = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-               "--master-addr", "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "2"] + SMALL,
+               "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2"] + SMALL,
               env={"PT_BENCH_BACKEND": "gloo"})
     check_contract(out, 2)
     assert "cpu_baseline" not in out
