@@ -406,11 +406,16 @@ struct Scan { Best best; bool unsure; V3 nd; float len_d; };
 template <bool FAST>
 PT_DEV void scan_begin(Scan &st, V3 d)
 {
-    const float INF = __builtin_inff();
-    st.best = {-4, INF, INF, 0.0f, 0.0f};
-    st.unsure = false;
+    // no candidate yet: brackets that compare false with everything, so that the first
+    // hit is taken whatever its distance (an overflowed, infinite one included), as
+    // src/main.cpp:61 takes it
+    const float NONE = __builtin_nanf("");
+    st.best = {-4, NONE, NONE, 0.0f, 0.0f};
     st.nd = -d;
     st.len_d = __builtin_amdgcn_sqrtf(Num<FAST>::dot(d, d));
+    // distances are estimated as t * |d|: a direction whose squared length leaves the
+    // normal range (or is not a number) gets no estimates, only the direct evaluation
+    st.unsure = !FAST && !(st.len_d >= 1e-18f && st.len_d <= 1e18f);
 }
 
 // One surface against the ray: i = its index in scene order.  Surfaces must
@@ -478,7 +483,7 @@ PT_DEV void scan_surface(Scan &st, int i, const GeomRec &rec, V3 o, V3 d)
     }
     // src/main.cpp:61: a later surface replaces the current one only when strictly closer;
     // a candidate that is not a hit never wins and never ties
-    const bool closer = acc & (c_hi < best.lo);
+    const bool closer = acc & !(c_hi >= best.lo);
     if constexpr (!FAST) {
         const bool not_closer = !acc | (c_lo >= best.hi);
         st.unsure = st.unsure | !(acc | rej) | !(closer | not_closer);

@@ -662,3 +662,50 @@ def test_combined_device_image_can_be_adopted_and_tone_mapped(ctx, pt):
     assert n == 16 and np.allclose(got, want, rtol=1e-5, atol=1e-5)
     rgb = ctx.tonemap_rgb8()
     assert np.abs(rgb.astype(int) - want_rgb.astype(int)).max() <= 1
+
+
+def test_extreme_magnitudes_and_non_finite_inputs(ctx, pt, orc):
+    """Coordinates from denormal to overflowing, rays with infinite and NaN components: every
+    path through the error-band filter either decides as the reference does or hands the ray to
+    the direct evaluation; results equal the oracle's bit for bit, NaNs included."""
+    rng = np.random.default_rng(1234)
+    scales = np.float32([1e-30, 1e-12, 1e-4, 1.0, 1.0, 1.0, 1e3, 1e9, 1e19])
+    n = 48
+    surf = np.zeros(n, dtype=pt.SURFACE)
+    surf["kind"] = rng.integers(0, 2, n)
+    ssurf = rng.choice(scales, n)[:, None]
+    surf["a"] = rng.uniform(-2, 2, (n, 3)) * ssurf
+    surf["b"] = surf["a"] + rng.uniform(-1, 1, (n, 3)) * ssurf
+    surf["c"] = surf["a"] + rng.uniform(-1, 1, (n, 3)) * ssurf
+    sph = surf["kind"] == pt.SPHERE
+    surf["b"][sph, 0] = (rng.uniform(0.1, 1.5, sph.sum()) * ssurf[sph, 0]).astype(np.float32)
+    surf["b"][np.flatnonzero(sph)[:2], 0] = [0.0, np.inf]                 # a point and an all-space sphere
+    mats = np.zeros(1, dtype=pt.MATERIAL)
+    osc = orc.Scene(surf.view(orc.SURFACE), mats.view(orc.MATERIAL), [0, 0, 0],
+                    orc.camera_init([0, 0, 0], 0, 0, 8, 0, 8, 8))
+    m = 60000
+    o = (rng.uniform(-3, 3, (m, 3)) * rng.choice(scales, (m, 1))).astype(np.float32)
+    d = (rng.normal(size=(m, 3)) * rng.choice(scales, (m, 1))).astype(np.float32)
+    # aim a third of the rays at surface anchors so that hits occur at every scale
+    k = rng.integers(0, n, m // 3)
+    with np.errstate(all="ignore"):
+        d[:m // 3] = (surf["a"][k] + 0.3 * (surf["b"][k] - surf["a"][k]) * (surf["kind"][k] == 0)[:, None] - o[:m // 3])
+    special = np.float32([np.inf, -np.inf, np.nan, 0.0, -0.0, 3.4e38, 1e-45])
+    rows = rng.integers(0, m, 3000)
+    o[rows[:1500], rng.integers(0, 3, 1500)] = rng.choice(special, 1500)
+    d[rows[1500:], rng.integers(0, 3, 1500)] = rng.choice(special, 1500)
+    with np.errstate(all="ignore"):
+        want = orc.intersect_rays(osc, o, d)
+    try:
+        for accel in (pt.ACCEL_NONE, pt.ACCEL_LDS_TILES):
+            ctx.set_accel(accel)
+            ctx.set_scene(surf, mats, [0, 0, 0])
+            got = ctx.intersect_rays(o, d)
+            bad = np.flatnonzero(got[0] != want[0])
+            assert bad.size == 0, "accel %d: %d indices differ, first ray %d: got %d want %d" % (
+                accel, bad.size, bad[0], got[0][bad[0]], want[0][bad[0]])
+            assert np.array_equal(got[1], want[1], equal_nan=True)
+            assert np.array_equal(got[2], want[2], equal_nan=True)
+    finally:
+        ctx.set_accel(pt.ACCEL_AUTO)
+    assert (want[0] >= 0).sum() > 3000 and len(np.unique(want[0])) > 15
