@@ -38,6 +38,17 @@ inline HostV3 hnormalize(HostV3 a)
     return {a.x * inv, a.y * inv, a.z * inv};
 }
 
+// A triangle outside the error-band filter's range (GEOM_DIRECT_EDGE_PRODUCT).
+bool extreme_triangle(const pt_surface &s)
+{
+    float m1 = 0, m2 = 0;
+    for (int k = 0; k < 3; k++) {
+        m1 = std::max(m1, std::fabs(s.b[k] - s.a[k]));
+        m2 = std::max(m2, std::fabs(s.c[k] - s.a[k]));
+    }
+    return !(m1 * m2 <= GEOM_DIRECT_EDGE_PRODUCT);      // also when not a number
+}
+
 uint32_t host_pcg(uint32_t v)
 {
     uint32_t s = v * 747796405u + 2891336453u;
@@ -65,6 +76,7 @@ struct pt_ctx {
     // hierarchy over the small triangles (n_bvh == 0: none) and the surfaces left outside it
     int accel = PT_ACCEL_AUTO;
     int n_bvh = 0, n_loose = 0;
+    float bvh_ray_reach = 0.0f;
     int *d_loose = nullptr;
     std::vector<pt_surface> host_surfaces;      // kept to rebuild when pt_set_accel changes
     float4 *d_bvh_nodes = nullptr;
@@ -192,7 +204,7 @@ int build_hierarchy(pt_ctx *ctx, const pt_surface *surfaces, int n_surfaces)
                 const float hi = std::max({surfaces[i].a[k], surfaces[i].b[k], surfaces[i].c[k]});
                 size += hi - lo;
             }
-            in = std::isfinite(size) && size <= 0.1f * spread;
+            in = std::isfinite(size) && size <= 0.1f * spread && !extreme_triangle(surfaces[i]);
         }
         (in ? inside : loose).push_back(i);
     }
@@ -208,6 +220,19 @@ int build_hierarchy(pt_ctx *ctx, const pt_surface *surfaces, int n_surfaces)
             cmin[k] = std::min(cmin[k], 0.5f * (lo + hi));
             cmax[k] = std::max(cmax[k], 0.5f * (lo + hi));
         }
+    // How far from the coordinate origin rays are expected to start: four times the scene's
+    // own extent (|x| + |y| + |z| over the finite surfaces); see BvhView::ray_reach.
+    float extent[3] = {0, 0, 0};
+    for (int i = 0; i < n_surfaces; i++) {
+        const pt_surface &s = surfaces[i];
+        for (int k = 0; k < 3; k++) {
+            float m = std::fabs(s.a[k]);
+            if (s.kind == PT_TRIANGLE) m = std::max({m, std::fabs(s.b[k]), std::fabs(s.c[k])});
+            else m += std::fabs(s.b[0]);
+            if (std::isfinite(m)) extent[k] = std::max(extent[k], m);
+        }
+    }
+    const float ray_reach = std::min(4.0f * (extent[0] + extent[1] + extent[2]), 1e30f);
     float3 gmin = make_float3(cmin[0], cmin[1], cmin[2]), ginv;
     ginv.x = cmax[0] > cmin[0] ? 1.0f / (cmax[0] - cmin[0]) : 0.0f;
     ginv.y = cmax[1] > cmin[1] ? 1.0f / (cmax[1] - cmin[1]) : 0.0f;
@@ -239,7 +264,7 @@ int build_hierarchy(pt_ctx *ctx, const pt_surface *surfaces, int n_surfaces)
 
     const unsigned blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_bvh_prepare, dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_geom, d_inside.p, n, gmin, ginv,
-                       d_keys.p, d_bmin.p, d_bmax.p);
+                       ray_reach, d_keys.p, d_bmin.p, d_bmax.p);
     HIP_TRY(ctx, hipGetLastError());
     size_t temp_bytes = 0;
     HIP_TRY(ctx, rocprim::radix_sort_keys(nullptr, temp_bytes, d_keys.p, d_sorted.p, (size_t)n, 0, 64, ctx->stream));
@@ -258,6 +283,7 @@ int build_hierarchy(pt_ctx *ctx, const pt_surface *surfaces, int n_surfaces)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_bvh = n;
     ctx->n_loose = (int)loose.size();
+    ctx->bvh_ray_reach = ray_reach;
     return PT_OK;
 }
 
@@ -272,6 +298,7 @@ SceneView scene_view(const pt_ctx *ctx)
     v.bvh.nodes = ctx->d_bvh_nodes;
     v.bvh.leaves = ctx->d_bvh_leaves;
     v.bvh.n_leaves = ctx->n_bvh;
+    v.bvh.ray_reach = ctx->bvh_ray_reach;
     memcpy(v.bg, ctx->bg, sizeof v.bg);
     return v;
 }
@@ -651,6 +678,7 @@ static int set_scene_body(pt_ctx *ctx, const pt_surface *surfaces, int32_t n_sur
             g[4] = e1.x; g[5] = e1.y; g[6] = e1.z;
             g[7] = e1.y * e2.z - e2.y * e1.z;
             g[8] = e2.x; g[9] = e2.y; g[10] = e2.z;
+            if (extreme_triangle(s)) g[7] = NAN;
             sh[8] = nrm.x; sh[9] = nrm.y; sh[10] = nrm.z;
             n_tri++;
         } else if (kind == PT_SPHERE) {

@@ -16,6 +16,7 @@ namespace ptd {
 //   q[2] = (right min xyz, -)         q[3] = (right max xyz, -)
 // A child ref >= 0 is an internal node, < 0 is leaf ~ref (position in Morton order).
 constexpr int BVH_NODE_QUADS = 4;
+constexpr float BVH_ORIGIN_ROUNDING = 8e-6f;     // of |o|: some 60 ulps
 // A leaf is one triangle: its geometry record (GEOM_STRIDE floats) with the
 // surface's index in scene order in element 3 (where a geometry record keeps the kind).
 constexpr int BVH_STACK = 64;        // deepest possible tree: 30 Morton bits + 32 index bits
@@ -35,6 +36,7 @@ struct BvhView {
     const float4 *nodes;     // n_leaves - 1 internal nodes, root = 0, in the first n_leaves records
     const float *leaves;     // n_leaves * GEOM_STRIDE, directly behind the nodes' n_leaves records
     int n_leaves;            // 0: the scene has no hierarchy
+    float ray_reach;         // the boxes allow for ray origins with |x| + |y| + |z| up to this
 };
 
 // ---------------------------------------------------------------- build
@@ -51,9 +53,11 @@ PT_DEV uint32_t spread10(uint32_t v)     // 10 bits -> every third bit
 // Per hierarchy triangle j (scene index tri_idx[j]): padded box, 64-bit sort key
 // = 30-bit Morton code of the centroid, then j (keys are unique).
 // The pad covers the reference's tolerance outside the triangle (u, v >= -1e-5
-// of an edge length) and the rounding of hit points.
+// of an edge length), the rounding of hit points, and the rounding of o - v0 in
+// the reference's test for ray origins up to ray_reach from the coordinate
+// origin (a hit it reports can lie off the triangle by a few ulps of |o|).
 __global__ void __launch_bounds__(256)
-k_bvh_prepare(const float *geom, const int *tri_idx, int n, float3 cmin, float3 cinv,
+k_bvh_prepare(const float *geom, const int *tri_idx, int n, float3 cmin, float3 cinv, float ray_reach,
               unsigned long long *keys, float4 *box_min, float4 *box_max)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -65,7 +69,7 @@ k_bvh_prepare(const float *geom, const int *tri_idx, int n, float3 cmin, float3 
     V3 hi = v3(fmaxf(v0.x, fmaxf(v1.x, v2.x)), fmaxf(v0.y, fmaxf(v1.y, v2.y)), fmaxf(v0.z, fmaxf(v1.z, v2.z)));
     const float size = (hi.x - lo.x) + (hi.y - lo.y) + (hi.z - lo.z);
     const float reach = fmaxf(fmaxf(fabsf(lo.x), fabsf(hi.x)), fmaxf(fmaxf(fabsf(lo.y), fabsf(hi.y)), fmaxf(fabsf(lo.z), fabsf(hi.z))));
-    const float pad = 1e-3f * size + 1e-5f * (1.0f + reach);
+    const float pad = 1e-3f * size + 1e-5f * (1.0f + reach) + BVH_ORIGIN_ROUNDING * ray_reach;
     box_min[j] = make_float4(lo.x - pad, lo.y - pad, lo.z - pad, 0.0f);
     box_max[j] = make_float4(hi.x + pad, hi.y + pad, hi.z + pad, 0.0f);
     const float cx = ((lo.x + hi.x) * 0.5f - cmin.x) * cinv.x;
@@ -178,8 +182,9 @@ k_bvh_leaves(const unsigned long long *keys, int n, const float *geom, const int
 // ---------------------------------------------------------------- traversal
 
 // Entry parameter of the ray into a box, or a negative value if it misses or
-// the box lies wholly beyond t_far.  inv = 1/d per component.
-PT_DEV float box_entry(float4 bmin, float4 bmax, V3 o, V3 inv, float t_far)
+// the box lies wholly beyond t_far.  inv = 1/d per component; slack widens the
+// test by the ray's own rounding (BvhCursor::slack).
+PT_DEV float box_entry(float4 bmin, float4 bmax, V3 o, V3 inv, float t_far, float slack)
 {
     const float x1 = (bmin.x - o.x) * inv.x, x2 = (bmax.x - o.x) * inv.x;
     const float y1 = (bmin.y - o.y) * inv.y, y2 = (bmax.y - o.y) * inv.y;
@@ -187,25 +192,63 @@ PT_DEV float box_entry(float4 bmin, float4 bmax, V3 o, V3 inv, float t_far)
     // fminf/fmaxf drop a NaN operand (0 * inf when the ray lies in a box face)
     const float t_in = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fmaxf(fminf(z1, z2), 0.0f));
     const float t_out = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fminf(fmaxf(z1, z2), t_far));
-    return t_in <= t_out ? t_in : -1.0f;
+    return t_in <= t_out + slack ? t_in : -1.0f;
 }
 
 // A lane's traversal in progress.
 struct BvhCursor {
     V3 inv;              // 1/d per component
     float len_d, inv_len;
+    float slack;         // in units of the ray parameter: what the origin's rounding can move a slab crossing
     int node;            // >= 0: internal node to open; < 0: leaf ~node to test
     int sp;              // entries on the stack
+    bool direct;         // the answer must come from the reference's scan over every surface
 };
 
+// The reference keeps the first hit it finds whatever its distance, replaces it
+// only by a strictly smaller one, and a distance that is not a number compares
+// false both ways (src/main.cpp:61): with such distances the answer depends on
+// the order in which the surfaces are visited, which a hierarchy does not keep.
+// So a ray whose origin is not finite or whose direction's length leaves the
+// normal range, a hit outside the hierarchy (`outside`) whose distance is not a
+// number, and (in bvh_test_leaf) a leaf hit whose distance is not finite all set
+// c.direct, and bvh_finish then scans every surface in scene order instead.
 template <bool FAST>
-PT_DEV void bvh_begin(BvhCursor &c, const BvhView &bvh, V3 d)
+PT_DEV void bvh_begin(BvhCursor &c, const BvhView &bvh, V3 o, V3 d, const Hit &outside)
 {
     c.inv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
     c.len_d = __builtin_amdgcn_sqrtf(Num<FAST>::dot(d, d));
     c.inv_len = __builtin_amdgcn_rcpf(c.len_d);
     c.sp = 0;
     c.node = bvh.n_leaves > 1 ? 0 : ~0;
+    c.direct = false;
+    c.slack = 0.0f;
+    if constexpr (!FAST) {
+        const float INF = __builtin_inff();
+        const float reach = __builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z);
+        c.direct = !(c.len_d >= 1e-18f && c.len_d <= 1e18f) | !(reach <= 1e18f) |
+                   ((outside.idx >= 0) & !(__builtin_fabsf(outside.dist) < INF));
+        // The boxes are padded for origins up to bvh.ray_reach away.  A ray from
+        // farther out widens every box test instead: a slab crossing (b - o) / d_k
+        // moves by the rounding of o over |d_k|; an axis the ray is parallel to
+        // (1/d_k infinite) has no crossing to move.  (One slack for all axes: such
+        // rays are slow, not wrong.)
+        if (reach > bvh.ray_reach) {
+            const float ix = __builtin_fabsf(c.inv.x), iy = __builtin_fabsf(c.inv.y), iz = __builtin_fabsf(c.inv.z);
+            const float steepest = fmaxf(fmaxf(ix < INF ? ix : 0.0f, iy < INF ? iy : 0.0f), iz < INF ? iz : 0.0f);
+            c.slack = BVH_ORIGIN_ROUNDING * reach * steepest;
+        }
+    }
+}
+
+// After the traversal: the closest hit overall.  geom, n_surfaces: every
+// surface's geometry record, for the rays that need the reference's own scan.
+template <bool FAST>
+PT_DEV void bvh_finish(const BvhCursor &c, cfloat_p geom, int n_surfaces, V3 o, V3 d, Hit &best)
+{
+    if constexpr (!FAST) {
+        if (c.direct) best = closest_direct<false>(geom, n_surfaces, o, d);
+    }
 }
 
 // Opens an internal node (its four quads): true when the traversal descends
@@ -215,8 +258,8 @@ PT_DEV bool bvh_open_node(BvhCursor &c, float4 q0, float4 q1, float4 q2, float4 
 {
     // nothing beyond the best distance can win; the margin covers the rounding of t * |d|
     const float t_far = best.dist * c.inv_len * (1.0f + 1e-5f);
-    const float tl = box_entry(q0, q1, o, c.inv, t_far);
-    const float tr = box_entry(q2, q3, o, c.inv, t_far);
+    const float tl = box_entry(q0, q1, o, c.inv, t_far, c.slack);
+    const float tr = box_entry(q2, q3, o, c.inv, t_far, c.slack);
     const int left = __float_as_int(q0.w), right = __float_as_int(q1.w);
     if (tl >= 0.0f && tr >= 0.0f) {                 // both: nearer first
         const bool left_first = tl <= tr;
@@ -232,7 +275,7 @@ PT_DEV bool bvh_open_node(BvhCursor &c, float4 q0, float4 q1, float4 q2, float4 
 
 // Tests a leaf (the first three quads of its record) against the best hit so far.
 template <bool FAST>
-PT_DEV void bvh_test_leaf(const BvhCursor &c, float4 g0, float4 g1, float4 g2, V3 o, V3 d, Hit &best)
+PT_DEV void bvh_test_leaf(BvhCursor &c, float4 g0, float4 g1, float4 g2, V3 o, V3 d, Hit &best)
 {
     using N = Num<FAST>;
     const V3 nd = -d;
@@ -263,6 +306,7 @@ PT_DEV void bvh_test_leaf(const BvhCursor &c, float4 g0, float4 g1, float4 g2, V
             ok = ok & !(te <= EPS_F);
             const V3 td = d * te;
             const float dist = __builtin_sqrtf(N::dot(td, td));
+            c.direct = c.direct | (ok & !(dist < __builtin_inff()));
             // smallest distance wins; equal distances: the earlier surface in scene order
             if (ok & ((dist < best.dist) | ((dist == best.dist) & (idx < best.idx) & (best.idx >= 0)))) {
                 best.idx = idx;
@@ -367,14 +411,18 @@ PT_DEV void bvh_fetch_records(const float4 *records, uint32_t rec, char *lds_wav
 
 // Continues a closest-hit search through the hierarchy.  On entry `best` is
 // the exact closest hit among the surfaces outside the hierarchy (idx < 0:
-// none, dist = +inf); on exit it is the closest hit overall, with the
-// reference's t and distance.
+// none); on exit it is the closest hit overall, with the reference's t and
+// distance (idx < 0: none, dist = +inf).
 template <bool FAST>
-PT_DEV void closest_in_bvh(const BvhView &bvh, V3 o, V3 d, Hit &best, int *stack, int stride)
+PT_DEV void closest_in_bvh(const BvhView &bvh, cfloat_p geom, int n_surfaces, V3 o, V3 d, Hit &best,
+                           int *stack, int stride)
 {
     BvhCursor c;
-    bvh_begin<FAST>(c, bvh, d);
-    while (bvh_step<FAST>(c, bvh, o, d, best, stack, stride)) {}
+    bvh_begin<FAST>(c, bvh, o, d, best);
+    if (best.idx < 0) best.dist = __builtin_inff();
+    if (!c.direct)
+        while (bvh_step<FAST>(c, bvh, o, d, best, stack, stride)) {}
+    bvh_finish<FAST>(c, geom, n_surfaces, o, d, best);
 }
 
 }  // namespace ptd

@@ -136,6 +136,15 @@ PT_DEV float rng_next(Rng &r) { return rng_at(r, r.ctr++); }
 // Element 7 is the first minor of both determinant(-d,e1,e2) and
 // determinant(b,e1,e2); it does not depend on the ray.
 constexpr int GEOM_STRIDE = 16;
+// Kinds in a geometry record.
+constexpr int GEOM_TRIANGLE = 0, GEOM_SPHERE = 1;
+// A triangle whose edges are so long that its determinants can leave the range
+// in which the hardware reciprocal is accurate (|det| up to 6 |d| |e1| |e2|;
+// v_rcp_f32 flushes a denormal result to zero) carries a NaN in element 7: every
+// estimate the error-band filter forms for it is then a NaN, no band decides,
+// and the ray is evaluated by closest_direct, which computes that minor itself.
+// (The FAST policy has no such fallback: it does not see these triangles.)
+constexpr float GEOM_DIRECT_EDGE_PRODUCT = 1e18f;     // |e1|max * |e2|max above this
 
 // Shading record, 12 floats per surface, read with per-lane indices.
 //  [0..2] color  [3] type | kind<<8  [4..6] emittance  [8..10] triangle normal | sphere position
@@ -279,7 +288,9 @@ template <bool FAST>
 PT_DEV bool triangle_direct(cfloat_p g, V3 o, V3 d, V3 nd, float &t_out, float &dist_out)
 {
     using N = Num<FAST>;
-    const TriDets q = triangle_dets<FAST>(g, o, nd);
+    // the record's element 7 is this same minor, or a NaN (see GEOM_DIRECT_EDGE_PRODUCT)
+    const V3 e1 = v3(g[4], g[5], g[6]), e2 = v3(g[8], g[9], g[10]);
+    const TriDets q = triangle_dets_v<FAST>(v3(g[0], g[1], g[2]), e1, N::msub(e1.y, e2.z, e2.y, e1.z), e2, o, nd);
     bool ok = !(q.det_a >= -EPS_F && q.det_a <= EPS_F);             // :53
     const float u = N::div(q.du, q.det_a);                          // :57
     ok = ok && !(u < -EPS_F || u >= 1.0f);                          // :58
@@ -351,7 +362,7 @@ PT_DEV Hit closest_direct(cfloat_p geom, int n_surfaces, V3 o, V3 d, const int *
         cfloat_p g = geom + (size_t)i * GEOM_STRIDE;
         float t, dist;
         bool ok;
-        if (__builtin_bit_cast(int, g[3]) == 0)      // wave-uniform branch
+        if (__builtin_bit_cast(int, g[3]) == GEOM_TRIANGLE)    // wave-uniform branch
             ok = triangle_direct<FAST>(g, o, d, nd, t, dist);
         else
             ok = sphere_direct<FAST>(g, o, d, t, dist);
@@ -430,7 +441,7 @@ PT_DEV void scan_surface(Scan &st, int i, const GeomRec &rec, V3 o, V3 d)
     bool rej;           // surely not a hit
     int mode;
     float c_lo, c_hi, a, b;
-    if (rec.kind == 0) {                         // wave-uniform branch
+    if (rec.kind == GEOM_TRIANGLE) {             // wave-uniform branch
         const TriDets q = triangle_dets_v<FAST>(v3(rec.q0.x, rec.q0.y, rec.q0.z), v3(rec.q1.x, rec.q1.y, rec.q1.z),
                                                 rec.q1.w, v3(rec.q2.x, rec.q2.y, rec.q2.z), o, st.nd);
         const float inv = __builtin_amdgcn_rcpf(q.det_a);

@@ -45,12 +45,12 @@ PT_DEV Hit closest_hit(const SceneView &sc, V3 o, V3 d, float *lds, unsigned lon
         return closest_intersection<FAST, NEED_DIST>(as_constant(sc.geom), sc.n_scan, o, d, redo_count);
     } else {
         Hit h = closest_intersection<FAST, true>(as_constant(sc.geom), sc.n_scan, o, d, redo_count, sc.loose);
-        if (h.idx < 0) h.dist = __builtin_inff();
         if constexpr (BVH_STACK_IN_LDS) {
-            closest_in_bvh<FAST>(sc.bvh, o, d, h, reinterpret_cast<int *>(lds) + threadIdx.x, BLOCK);
+            closest_in_bvh<FAST>(sc.bvh, as_constant(sc.geom), sc.n_surfaces, o, d, h,
+                                 reinterpret_cast<int *>(lds) + threadIdx.x, BLOCK);
         } else {
             int stack[BVH_STACK];
-            closest_in_bvh<FAST>(sc.bvh, o, d, h, stack, 1);
+            closest_in_bvh<FAST>(sc.bvh, as_constant(sc.geom), sc.n_surfaces, o, d, h, stack, 1);
         }
         if (h.idx < 0) h.dist = 0.0f;
         return h;
@@ -493,7 +493,7 @@ k_render_mega_bvh(RenderParams P)
     PathState ps = {v3(0, 0, 0), v3(0, 0, 1), v3(1, 1, 1), v3(0, 0, 0), {0, 0}, 0};
     Hit best = {-1, 0.0f, 0.0f};
     BvhCursor cur;
-    cur.node = 0; cur.sp = 0; cur.inv = v3(0, 0, 0); cur.len_d = 1.0f; cur.inv_len = 1.0f;
+    cur.node = 0; cur.sp = 0; cur.inv = v3(0, 0, 0); cur.len_d = 1.0f; cur.inv_len = 1.0f; cur.slack = 0.0f; cur.direct = false;
     int stack[BVH_STACK];
     bool alive = true;              // false: the queue is empty and this lane has nothing left
     bool traversing = false;        // false: waiting to shade / start a segment
@@ -533,8 +533,8 @@ k_render_mega_bvh(RenderParams P)
                 // the surfaces outside the hierarchy first, then the hierarchy
                 best = closest_intersection<FAST, true>(as_constant(P.scene.geom), P.scene.n_scan, ps.o, ps.d,
                                                         P.stats + 1, P.scene.loose);
+                bvh_begin<FAST>(cur, P.scene.bvh, ps.o, ps.d, best);
                 if (best.idx < 0) best.dist = __builtin_inff();
-                bvh_begin<FAST>(cur, P.scene.bvh, ps.d);
                 traversing = true;
                 n_seg++;
             }
@@ -543,7 +543,9 @@ k_render_mega_bvh(RenderParams P)
         bvh_fetch_records(P.scene.bvh.nodes, traversing ? bvh_record_of(P.scene.bvh, cur.node) : 0u, lds_wave,
                           q0, q1, q2, q3);
         if (traversing) {
-            if (!bvh_advance<FAST>(cur, q0, q1, q2, q3, ps.o, ps.d, best, stack, 1)) {
+            // (a ray that needs the reference's own scan skips the traversal)
+            if (cur.direct || !bvh_advance<FAST>(cur, q0, q1, q2, q3, ps.o, ps.d, best, stack, 1)) {
+                bvh_finish<FAST>(cur, as_constant(P.scene.geom), P.scene.n_surfaces, ps.o, ps.d, best);
                 traversing = false;
                 have_hit = true;
             }

@@ -709,3 +709,49 @@ def test_extreme_magnitudes_and_non_finite_inputs(ctx, pt, orc):
     finally:
         ctx.set_accel(pt.ACCEL_AUTO)
     assert (want[0] >= 0).sum() > 3000 and len(np.unique(want[0])) > 15
+
+
+def test_hierarchy_with_extreme_magnitudes(ctx, pt, orc):
+    """The hierarchy over triangles whose sizes and positions span many orders of magnitude,
+    queried with rays of every scale and with non-finite components: the same answers as the
+    oracle's scan."""
+    rng = np.random.default_rng(4321)
+    scales = np.float32([1e-12, 1e-4, 1e-2, 1.0, 1.0, 1.0, 1e3, 1e9, 1e18])
+    n = 900
+    surf = np.zeros(n, dtype=pt.SURFACE)
+    ssurf = rng.choice(scales, n)[:, None]
+    centre = rng.choice(scales, n)[:, None] * rng.uniform(-2, 2, (n, 3))
+    surf["a"] = centre
+    surf["b"] = centre + rng.uniform(-1, 1, (n, 3)) * ssurf
+    surf["c"] = centre + rng.uniform(-1, 1, (n, 3)) * ssurf
+    surf["kind"][:6] = pt.SPHERE                        # a few spheres stay outside the hierarchy
+    surf["b"][:6, 0] = [0.5, 1e-3, 1e3, 2.0, 1e9, 0.1]
+    mats = np.zeros(1, dtype=pt.MATERIAL)
+    osc = orc.Scene(surf.view(orc.SURFACE), mats.view(orc.MATERIAL), [0, 0, 0],
+                    orc.camera_init([0, 0, 0], 0, 0, 8, 0, 8, 8))
+    m = 40000
+    o = (rng.uniform(-3, 3, (m, 3)) * rng.choice(scales, (m, 1))).astype(np.float32)
+    d = (rng.normal(size=(m, 3)) * rng.choice(scales, (m, 1))).astype(np.float32)
+    k = rng.integers(0, n, m // 2)                      # half of the rays aim at a triangle's inside
+    with np.errstate(all="ignore"):
+        target = surf["a"][k] + 0.3 * (surf["b"][k] - surf["a"][k]) + 0.3 * (surf["c"][k] - surf["a"][k])
+        d[:m // 2] = target - o[:m // 2]
+    special = np.float32([np.inf, -np.inf, np.nan, 0.0, -0.0, 3.4e38, 1e-45])
+    rows = rng.integers(0, m, 2000)
+    o[rows[:1000], rng.integers(0, 3, 1000)] = rng.choice(special, 1000)
+    d[rows[1000:], rng.integers(0, 3, 1000)] = rng.choice(special, 1000)
+    with np.errstate(all="ignore"):
+        want = orc.intersect_rays(osc, o, d)
+    try:
+        ctx.set_accel(pt.ACCEL_BVH)
+        ctx.set_scene(surf, mats, [0, 0, 0])
+        got = ctx.intersect_rays(o, d)
+        assert ctx.counters().accel == pt.ACCEL_BVH
+        bad = np.flatnonzero(got[0] != want[0])
+        assert bad.size == 0, "%d indices differ, first ray %d: got %d want %d" % (
+            bad.size, bad[0], got[0][bad[0]], want[0][bad[0]])
+        assert np.array_equal(got[1], want[1], equal_nan=True)
+        assert np.array_equal(got[2], want[2], equal_nan=True)
+    finally:
+        ctx.set_accel(pt.ACCEL_AUTO)
+    assert (want[0] >= 0).sum() > 3000 and len(np.unique(want[0])) > 200
