@@ -755,3 +755,15 @@ def test_hierarchy_with_extreme_magnitudes(ctx, pt, orc):
     finally:
         ctx.set_accel(pt.ACCEL_AUTO)
     assert (want[0] >= 0).sum() > 3000 and len(np.unique(want[0])) > 200
+
+
+def test_soak_of_random_scenes_short():
+    """tools/soak_parity.py (random clustered scenes, rays aimed at edges and vertices, origins on
+    surfaces; scan, hierarchy and LDS tiles against the oracle) on a few seeds."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_parity.py"), "6", "60000"],
+                       capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    assert "360000 rays x 3 modes, 0 mismatches" in p.stdout
