@@ -202,6 +202,8 @@ struct BvhCursor {
     float slack;         // in units of the ray parameter: what the origin's rounding can move a slab crossing
     int node;            // >= 0: internal node to open; < 0: leaf ~node to test
     int sp;              // entries on the stack
+    int top;             // the newest entry, kept in a register: a pop then costs no memory
+                         // round trip (the entry below it is fetched while the popped node is)
     bool direct;         // the answer must come from the reference's scan over every surface
 };
 
@@ -220,6 +222,7 @@ PT_DEV void bvh_begin(BvhCursor &c, const BvhView &bvh, V3 o, V3 d, const Hit &o
     c.len_d = __builtin_amdgcn_sqrtf(Num<FAST>::dot(d, d));
     c.inv_len = __builtin_amdgcn_rcpf(c.len_d);
     c.sp = 0;
+    c.top = 0;
     c.node = bvh.n_leaves > 1 ? 0 : ~0;
     c.direct = false;
     c.slack = 0.0f;
@@ -263,7 +266,8 @@ PT_DEV bool bvh_open_node(BvhCursor &c, float4 q0, float4 q1, float4 q2, float4 
     const int left = __float_as_int(q0.w), right = __float_as_int(q1.w);
     if (tl >= 0.0f && tr >= 0.0f) {                 // both: nearer first
         const bool left_first = tl <= tr;
-        stack[c.sp * stride] = left_first ? right : left;
+        if (c.sp > 0) stack[(c.sp - 1) * stride] = c.top;
+        c.top = left_first ? right : left;
         c.sp++;
         c.node = left_first ? left : right;
         return true;
@@ -322,7 +326,8 @@ PT_DEV bool bvh_pop(BvhCursor &c, const int *stack, int stride)
 {
     if (c.sp == 0) return false;
     c.sp--;
-    c.node = stack[c.sp * stride];
+    c.node = c.top;
+    if (c.sp > 0) c.top = stack[(c.sp - 1) * stride];
     return true;
 }
 

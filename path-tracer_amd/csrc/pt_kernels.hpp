@@ -479,10 +479,10 @@ k_render_mega(RenderParams P)
 // or leaf.  The records of a step are fetched by the wave as a whole
 // (bvh_fetch_records), which needs all 64 lanes: a lane that finds the queue
 // empty stays in the loop, idle, until the whole wave is done.
-// (79 VGPRs: 6 waves per SIMD.  Forced down to 64 VGPRs for 8 waves, the kernel
-// spills and was measured 9 % slower.)
+// (Held to 80 VGPRs, 6 waves per SIMD: left alone it takes 83 and runs 5, measured
+// 5 % slower; forced down to 64 VGPRs for 8 waves it spills, 9 % slower.)
 template <bool FAST>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6)))
 k_render_mega_bvh(RenderParams P)
 {
     __shared__ __align__(16) char fetch_lds[(BLOCK / 64) * BVH_FETCH_LDS];
@@ -493,7 +493,7 @@ k_render_mega_bvh(RenderParams P)
     PathState ps = {v3(0, 0, 0), v3(0, 0, 1), v3(1, 1, 1), v3(0, 0, 0), {0, 0}, 0};
     Hit best = {-1, 0.0f, 0.0f};
     BvhCursor cur;
-    cur.node = 0; cur.sp = 0; cur.inv = v3(0, 0, 0); cur.len_d = 1.0f; cur.inv_len = 1.0f; cur.slack = 0.0f; cur.direct = false;
+    cur.node = 0; cur.sp = 0; cur.top = 0; cur.inv = v3(0, 0, 0); cur.len_d = 1.0f; cur.inv_len = 1.0f; cur.slack = 0.0f; cur.direct = false;
     int stack[BVH_STACK];
     bool alive = true;              // false: the queue is empty and this lane has nothing left
     bool traversing = false;        // false: waiting to shade / start a segment
