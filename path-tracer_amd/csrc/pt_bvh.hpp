@@ -207,6 +207,26 @@ struct BvhCursor {
     bool direct;         // the answer must come from the reference's scan over every surface
 };
 
+// The best candidate of a traversal in progress.
+//   ref >= 0: a surface outside the hierarchy, by scene index;
+//   ref <  0: leaf ~ref (position in Morton order);  BVH_NO_HIT: none yet.
+// EXACT: [lo, hi] brackets the distance the reference computes for it; lo == hi
+// when that distance is known exactly (every candidate from outside the
+// hierarchy, and leaves that had to be evaluated exactly).  A leaf is evaluated
+// exactly - three IEEE divisions and a root - only when the error-band filter
+// cannot decide; the winner's t and distance are computed once, in bvh_finish.
+// FAST: ref is always a scene index, lo the distance and hi the ray parameter.
+struct BvhBest { int ref; float lo, hi; };
+constexpr int BVH_NO_HIT = (int)0x80000000;
+
+template <bool FAST>
+PT_DEV BvhBest bvh_best_from(const Hit &outside)
+{
+    const float INF = __builtin_inff();
+    if (outside.idx < 0) return {BVH_NO_HIT, INF, INF};
+    return {outside.idx, outside.dist, FAST ? outside.t : outside.dist};
+}
+
 // The reference keeps the first hit it finds whatever its distance, replaces it
 // only by a strictly smaller one, and a distance that is not a number compares
 // false both ways (src/main.cpp:61): with such distances the answer depends on
@@ -244,23 +264,65 @@ PT_DEV void bvh_begin(BvhCursor &c, const BvhView &bvh, V3 o, V3 d, const Hit &o
     }
 }
 
-// After the traversal: the closest hit overall.  geom, n_surfaces: every
-// surface's geometry record, for the rays that need the reference's own scan.
-template <bool FAST>
-PT_DEV void bvh_finish(const BvhCursor &c, cfloat_p geom, int n_surfaces, V3 o, V3 d, Hit &best)
+// The exact evaluation of one leaf triangle (record quads g0..g2), as
+// Triangle::intersects does it (src/surface.hpp:53-70).
+PT_DEV bool bvh_leaf_exact(const TriDets &q, V3 d, float &t, float &dist)
 {
-    if constexpr (!FAST) {
-        if (c.direct) best = closest_direct<false>(geom, n_surfaces, o, d);
+    bool ok = !(q.det_a >= -EPS_F && q.det_a <= EPS_F);
+    const float ue = q.du / q.det_a;
+    ok = ok & !(ue < -EPS_F || ue >= 1.0f);
+    const float ve = q.dv / q.det_a;
+    ok = ok & !(ve < -EPS_F || ue + ve >= 1.0f);
+    t = q.dt / q.det_a;
+    ok = ok & !(t <= EPS_F);
+    const V3 td = d * t;
+    dist = __builtin_sqrtf(Num<false>::dot(td, td));
+    return ok;
+}
+
+PT_DEV TriDets bvh_leaf_dets(const BvhView &bvh, int leaf, V3 o, V3 d, int &scene_index)
+{
+    const float4 *g = reinterpret_cast<const float4 *>(bvh.leaves + (size_t)leaf * GEOM_STRIDE);
+    const float4 g0 = g[0], g1 = g[1], g2 = g[2];
+    scene_index = __float_as_int(g0.w);
+    return triangle_dets_v<false>(v3(g0.x, g0.y, g0.z), v3(g1.x, g1.y, g1.z), g1.w, v3(g2.x, g2.y, g2.z), o, -d);
+}
+
+// After the traversal: the closest hit overall, with the reference's t and
+// distance (idx < 0: none).  geom, n_surfaces: every surface's geometry record.
+template <bool FAST>
+PT_DEV Hit bvh_finish(const BvhCursor &c, const BvhView &bvh, const float *geom, int n_surfaces, V3 o, V3 d,
+                      const BvhBest &best)
+{
+    Hit h = {-1, 0.0f, 0.0f};
+    if constexpr (FAST) {
+        if (best.ref != BVH_NO_HIT) h = {best.ref, best.hi, best.lo};
+        return h;
+    } else {
+        if (c.direct) return closest_direct<false>(as_constant(geom), n_surfaces, o, d);
+        if (best.ref == BVH_NO_HIT) return h;
+        if (best.ref >= 0) {
+            // a surface outside the hierarchy won: its t again (its distance is best.lo)
+            cfloat_p g = as_constant(geom + (size_t)best.ref * GEOM_STRIDE);
+            h.idx = best.ref;
+            if (__builtin_bit_cast(int, g[3]) == GEOM_TRIANGLE) triangle_direct<false>(g, o, d, -d, h.t, h.dist);
+            else sphere_direct<false>(g, o, d, h.t, h.dist);
+        } else {
+            const TriDets q = bvh_leaf_dets(bvh, ~best.ref, o, d, h.idx);
+            bvh_leaf_exact(q, d, h.t, h.dist);
+        }
+        return h;
     }
 }
 
 // Opens an internal node (its four quads): true when the traversal descends
 // into a child (c.node), false when neither child can hold a closer hit.
-PT_DEV bool bvh_open_node(BvhCursor &c, float4 q0, float4 q1, float4 q2, float4 q3, V3 o, const Hit &best,
+PT_DEV bool bvh_open_node(BvhCursor &c, float4 q0, float4 q1, float4 q2, float4 q3, V3 o, float bound,
                           int *stack, int stride)
 {
-    // nothing beyond the best distance can win; the margin covers the rounding of t * |d|
-    const float t_far = best.dist * c.inv_len * (1.0f + 1e-5f);
+    // nothing beyond `bound`, an upper bound of the best distance, can win; the margin
+    // covers the rounding of t * |d|
+    const float t_far = bound * c.inv_len * (1.0f + 1e-5f);
     const float tl = box_entry(q0, q1, o, c.inv, t_far, c.slack);
     const float tr = box_entry(q2, q3, o, c.inv, t_far, c.slack);
     const int left = __float_as_int(q0.w), right = __float_as_int(q1.w);
@@ -277,11 +339,10 @@ PT_DEV bool bvh_open_node(BvhCursor &c, float4 q0, float4 q1, float4 q2, float4 
     return false;
 }
 
-// Tests a leaf (the first three quads of its record) against the best hit so far.
+// Tests leaf ~c.node (the first three quads of its record) against the best candidate so far.
 template <bool FAST>
-PT_DEV void bvh_test_leaf(BvhCursor &c, float4 g0, float4 g1, float4 g2, V3 o, V3 d, Hit &best)
+PT_DEV void bvh_test_leaf(BvhCursor &c, const BvhView &bvh, float4 g0, float4 g1, float4 g2, V3 o, V3 d, BvhBest &best)
 {
-    using N = Num<FAST>;
     const V3 nd = -d;
     const int idx = __float_as_int(g0.w);
     const TriDets q = triangle_dets_v<FAST>(v3(g0.x, g0.y, g0.z), v3(g1.x, g1.y, g1.z), g1.w,
@@ -289,35 +350,40 @@ PT_DEV void bvh_test_leaf(BvhCursor &c, float4 g0, float4 g1, float4 g2, V3 o, V
     const float rinv = __builtin_amdgcn_rcpf(q.det_a);
     const float u = q.du * rinv, v = q.dv * rinv, t = q.dt * rinv;
     const float s = u + v;
-    const bool det_bad = q.det_a >= -EPS_F && q.det_a <= EPS_F;
+    const bool det_bad = __builtin_fabsf(q.det_a) <= EPS_F;
+    const float dist = t * c.len_d;
     if constexpr (FAST) {
         const bool acc = !(det_bad | (u < -EPS_F) | (u >= 1.0f) | (v < -EPS_F) | (s >= 1.0f) | (t <= EPS_F));
-        const float dist = t * c.len_d;
-        if (acc & (dist < best.dist)) { best.idx = idx; best.t = t; best.dist = dist; }
+        if (acc & (dist < best.lo)) best = {idx, dist, t};
     } else {
-        const bool rej = det_bad | (u < BAND_LO_REJ) | (u > BAND_ONE_REJ) | (v < BAND_LO_REJ) |
-                         (s > BAND_ONE_REJ) | (t < BAND_T_REJ);
-        // a sure hit farther than the best, by more than the error of the estimate, cannot win
-        const bool farther = t * c.len_d * (1.0f - TRI_DIST_ERR) > best.dist;
-        if (!(rej | farther)) {
-            // exact evaluation, as Triangle::intersects does it (src/surface.hpp:53-70)
-            bool ok = !det_bad;
-            const float ue = q.du / q.det_a;
-            ok = ok & !(ue < -EPS_F || ue >= 1.0f);
-            const float ve = q.dv / q.det_a;
-            ok = ok & !(ve < -EPS_F || ue + ve >= 1.0f);
-            const float te = q.dt / q.det_a;
-            ok = ok & !(te <= EPS_F);
-            const V3 td = d * te;
-            const float dist = __builtin_sqrtf(N::dot(td, td));
-            c.direct = c.direct | (ok & !(dist < __builtin_inff()));
-            // smallest distance wins; equal distances: the earlier surface in scene order
-            if (ok & ((dist < best.dist) | ((dist == best.dist) & (idx < best.idx) & (best.idx >= 0)))) {
-                best.idx = idx;
-                best.t = te;
-                best.dist = dist;
+        // the same bands as the scan's filter (scan_surface)
+        const float low_uv = __builtin_fminf(u, v);
+        const bool rej = det_bad | (low_uv < BAND_LO_REJ) | (__builtin_fmaxf(u, s) > BAND_ONE_REJ) | (t < BAND_T_REJ);
+        const bool acc = !det_bad & (low_uv > BAND_LO_ACC) & (u < BAND_ONE_ACC) & (s < BAND_ONE_ACC) & (t > BAND_T_ACC);
+        const float c_lo = dist * (1.0f - TRI_DIST_ERR), c_hi = dist * (1.0f + TRI_DIST_ERR);
+        // surely no hit, or (if a hit at all) surely farther than the best
+        if (rej | (c_lo > best.hi)) return;
+        if (acc & (c_hi < best.lo)) {               // surely a hit and surely closer
+            best = {c.node, c_lo, c_hi};
+            return;
+        }
+        // Rare: a value inside a band, or distances too close to tell apart.  Both
+        // candidates exactly; equal distances go to the earlier surface in scene order.
+        float te, dist_e;
+        const bool ok = bvh_leaf_exact(q, d, te, dist_e);
+        c.direct = c.direct | (ok & !(dist_e < __builtin_inff()));
+        if (!ok) return;
+        int best_idx = best.ref;
+        if (best.ref < 0 && best.ref != BVH_NO_HIT) {
+            const TriDets qb = bvh_leaf_dets(bvh, ~best.ref, o, d, best_idx);
+            if (best.lo != best.hi) {
+                float tb, dist_b;
+                bvh_leaf_exact(qb, d, tb, dist_b);
+                best.lo = best.hi = dist_b;
             }
         }
+        if ((dist_e < best.lo) | ((dist_e == best.lo) & (idx < best_idx) & (best.ref != BVH_NO_HIT)))
+            best = {c.node, dist_e, dist_e};
     }
 }
 
@@ -333,29 +399,29 @@ PT_DEV bool bvh_pop(BvhCursor &c, const int *stack, int stride)
 
 // Advances a traversal by one node or one leaf, given the record c.node names.
 template <bool FAST>
-PT_DEV bool bvh_advance(BvhCursor &c, float4 q0, float4 q1, float4 q2, float4 q3, V3 o, V3 d, Hit &best,
-                        int *stack, int stride)
+PT_DEV bool bvh_advance(BvhCursor &c, const BvhView &bvh, float4 q0, float4 q1, float4 q2, float4 q3, V3 o, V3 d,
+                        BvhBest &best, int *stack, int stride)
 {
     if (c.node >= 0) {
-        if (bvh_open_node(c, q0, q1, q2, q3, o, best, stack, stride)) return true;
+        if (bvh_open_node(c, q0, q1, q2, q3, o, FAST ? best.lo : best.hi, stack, stride)) return true;
     } else {
-        bvh_test_leaf<FAST>(c, q0, q1, q2, o, d, best);
+        bvh_test_leaf<FAST>(c, bvh, q0, q1, q2, o, d, best);
     }
     return bvh_pop(c, stack, stride);
 }
 
-// Advances a traversal by one node or one leaf.  `best` is the exact closest
-// hit so far (idx < 0: none, dist = +inf).  Returns false when the traversal
-// is complete.  stack: BVH_STACK ints per lane, lane-strided (stack[level * stride]).
+// Advances a traversal by one node or one leaf.  Returns false when the
+// traversal is complete.  stack: BVH_STACK ints per lane, lane-strided
+// (stack[level * stride]).
 template <bool FAST>
-PT_DEV bool bvh_step(BvhCursor &c, const BvhView &bvh, V3 o, V3 d, Hit &best, int *stack, int stride)
+PT_DEV bool bvh_step(BvhCursor &c, const BvhView &bvh, V3 o, V3 d, BvhBest &best, int *stack, int stride)
 {
     if (c.node >= 0) {
         const float4 *q = bvh.nodes + (size_t)c.node * BVH_NODE_QUADS;
-        if (bvh_open_node(c, q[0], q[1], q[2], q[3], o, best, stack, stride)) return true;
+        if (bvh_open_node(c, q[0], q[1], q[2], q[3], o, FAST ? best.lo : best.hi, stack, stride)) return true;
     } else {
         const float4 *g = reinterpret_cast<const float4 *>(bvh.leaves + (size_t)(~c.node) * GEOM_STRIDE);
-        bvh_test_leaf<FAST>(c, g[0], g[1], g[2], o, d, best);
+        bvh_test_leaf<FAST>(c, bvh, g[0], g[1], g[2], o, d, best);
     }
     return bvh_pop(c, stack, stride);
 }
@@ -414,20 +480,20 @@ PT_DEV void bvh_fetch_records(const float4 *records, uint32_t rec, char *lds_wav
     q0 = mine[0]; q1 = mine[1]; q2 = mine[2]; q3 = mine[3];
 }
 
-// Continues a closest-hit search through the hierarchy.  On entry `best` is
+// Continues a closest-hit search through the hierarchy.  On entry `hit` is
 // the exact closest hit among the surfaces outside the hierarchy (idx < 0:
 // none); on exit it is the closest hit overall, with the reference's t and
-// distance (idx < 0: none, dist = +inf).
+// distance (idx < 0: none).
 template <bool FAST>
-PT_DEV void closest_in_bvh(const BvhView &bvh, cfloat_p geom, int n_surfaces, V3 o, V3 d, Hit &best,
+PT_DEV void closest_in_bvh(const BvhView &bvh, const float *geom, int n_surfaces, V3 o, V3 d, Hit &hit,
                            int *stack, int stride)
 {
     BvhCursor c;
-    bvh_begin<FAST>(c, bvh, o, d, best);
-    if (best.idx < 0) best.dist = __builtin_inff();
+    bvh_begin<FAST>(c, bvh, o, d, hit);
+    BvhBest best = bvh_best_from<FAST>(hit);
     if (!c.direct)
         while (bvh_step<FAST>(c, bvh, o, d, best, stack, stride)) {}
-    bvh_finish<FAST>(c, geom, n_surfaces, o, d, best);
+    hit = bvh_finish<FAST>(c, bvh, geom, n_surfaces, o, d, best);
 }
 
 }  // namespace ptd

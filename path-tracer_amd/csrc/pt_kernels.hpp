@@ -46,11 +46,11 @@ PT_DEV Hit closest_hit(const SceneView &sc, V3 o, V3 d, float *lds, unsigned lon
     } else {
         Hit h = closest_intersection<FAST, true>(as_constant(sc.geom), sc.n_scan, o, d, redo_count, sc.loose);
         if constexpr (BVH_STACK_IN_LDS) {
-            closest_in_bvh<FAST>(sc.bvh, as_constant(sc.geom), sc.n_surfaces, o, d, h,
+            closest_in_bvh<FAST>(sc.bvh, sc.geom, sc.n_surfaces, o, d, h,
                                  reinterpret_cast<int *>(lds) + threadIdx.x, BLOCK);
         } else {
             int stack[BVH_STACK];
-            closest_in_bvh<FAST>(sc.bvh, as_constant(sc.geom), sc.n_surfaces, o, d, h, stack, 1);
+            closest_in_bvh<FAST>(sc.bvh, sc.geom, sc.n_surfaces, o, d, h, stack, 1);
         }
         if (h.idx < 0) h.dist = 0.0f;
         return h;
@@ -491,7 +491,7 @@ k_render_mega_bvh(RenderParams P)
     WorkPool pool = {0, 0, false};
     ItemState it = {false, 0, 0, 0, 0, 0, 0, 0, v3(0, 0, 0)};
     PathState ps = {v3(0, 0, 0), v3(0, 0, 1), v3(1, 1, 1), v3(0, 0, 0), {0, 0}, 0};
-    Hit best = {-1, 0.0f, 0.0f};
+    BvhBest best = {BVH_NO_HIT, 0.0f, 0.0f};
     BvhCursor cur;
     cur.node = 0; cur.sp = 0; cur.top = 0; cur.inv = v3(0, 0, 0); cur.len_d = 1.0f; cur.inv_len = 1.0f; cur.slack = 0.0f; cur.direct = false;
     int stack[BVH_STACK];
@@ -510,8 +510,10 @@ k_render_mega_bvh(RenderParams P)
             if (waits) {
                 need_path = !have_hit;
                 if (have_hit) {
-                    if (best.idx < 0) best.dist = 0.0f;
-                    if (shade_hit<FAST>(ps, P.scene, shade, best)) {
+                    // the winner's t and distance, once per segment (bvh_finish), then shading
+                    Hit h = bvh_finish<FAST>(cur, P.scene.bvh, P.scene.geom, P.scene.n_surfaces, ps.o, ps.d, best);
+                    if (h.idx < 0) h.dist = 0.0f;
+                    if (shade_hit<FAST>(ps, P.scene, shade, h)) {
                         it.sum = it.sum + ps.col;            // buffer[u][v] += color, main.cpp:139
                         it.s++;
                         need_path = true;
@@ -531,10 +533,10 @@ k_render_mega_bvh(RenderParams P)
             if (waits && alive) {
                 if (need_path) path_begin(ps, P.cam, it.pixel_key, it.s, it.px, it.py);
                 // the surfaces outside the hierarchy first, then the hierarchy
-                best = closest_intersection<FAST, true>(as_constant(P.scene.geom), P.scene.n_scan, ps.o, ps.d,
-                                                        P.stats + 1, P.scene.loose);
-                bvh_begin<FAST>(cur, P.scene.bvh, ps.o, ps.d, best);
-                if (best.idx < 0) best.dist = __builtin_inff();
+                const Hit outside = closest_intersection<FAST, true>(as_constant(P.scene.geom), P.scene.n_scan,
+                                                                     ps.o, ps.d, P.stats + 1, P.scene.loose);
+                bvh_begin<FAST>(cur, P.scene.bvh, ps.o, ps.d, outside);
+                best = bvh_best_from<FAST>(outside);
                 traversing = true;
                 n_seg++;
             }
@@ -544,8 +546,7 @@ k_render_mega_bvh(RenderParams P)
                           q0, q1, q2, q3);
         if (traversing) {
             // (a ray that needs the reference's own scan skips the traversal)
-            if (cur.direct || !bvh_advance<FAST>(cur, q0, q1, q2, q3, ps.o, ps.d, best, stack, 1)) {
-                bvh_finish<FAST>(cur, as_constant(P.scene.geom), P.scene.n_surfaces, ps.o, ps.d, best);
+            if (cur.direct || !bvh_advance<FAST>(cur, P.scene.bvh, q0, q1, q2, q3, ps.o, ps.d, best, stack, 1)) {
                 traversing = false;
                 have_hit = true;
             }
