@@ -171,6 +171,7 @@ int check_ready(pt_ctx *ctx, bool need_camera)
 // it when the scene has too few of them (or PT_ACCEL_NONE is set).  geom is
 // the host copy of the geometry records already uploaded to ctx->d_geom.
 constexpr int BVH_AUTO_MIN_TRIANGLES = 256;
+constexpr int SPHERE_SKIP_MIN_SPHERES = 16;
 
 int build_hierarchy(pt_ctx *ctx, const pt_surface *surfaces, int n_surfaces)
 {
@@ -339,6 +340,10 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
 
     // scenes with a hierarchy have a megakernel of their own
     void (*kernel)(RenderParams) = &k_render_mega<FAST, KIND>;
+    if constexpr (KIND != SCENE_BVH) {
+        // many spheres: most waves miss most of them (see scan_surface)
+        if (ctx->n_sph >= SPHERE_SKIP_MIN_SPHERES) kernel = &k_render_mega<FAST, KIND, true>;
+    }
     if constexpr (KIND == SCENE_BVH) kernel = &k_render_mega_bvh<FAST>;
     int blocks_per_cu = 0;
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, BLOCK, lds_bytes));

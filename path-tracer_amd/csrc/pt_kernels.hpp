@@ -38,11 +38,11 @@ constexpr int SCENE_BVH = 2;      // shading records from global memory, scan + 
 // lds: the kernel's dynamic LDS; a hierarchy scene keeps the traversal stacks
 // there, BVH_STACK levels of BLOCK lanes (level-major, so a level's 64 lanes
 // fall in 64 different banks).
-template <bool FAST, bool NEED_DIST, int KIND>
+template <bool FAST, bool NEED_DIST, int KIND, bool WAVE_SKIP = false>
 PT_DEV Hit closest_hit(const SceneView &sc, V3 o, V3 d, float *lds, unsigned long long *redo_count = nullptr)
 {
     if constexpr (KIND != SCENE_BVH) {
-        return closest_intersection<FAST, NEED_DIST>(as_constant(sc.geom), sc.n_scan, o, d, redo_count);
+        return closest_intersection<FAST, NEED_DIST, WAVE_SKIP>(as_constant(sc.geom), sc.n_scan, o, d, redo_count);
     } else {
         Hit h = closest_intersection<FAST, true>(as_constant(sc.geom), sc.n_scan, o, d, redo_count, sc.loose);
         if constexpr (BVH_STACK_IN_LDS) {
@@ -331,11 +331,11 @@ PT_DEV bool shade_hit(PathState &ps, const SceneView &sc, const float *shade, co
     return ended;
 }
 
-template <bool FAST, int KIND>
+template <bool FAST, int KIND, bool WAVE_SKIP = false>
 PT_DEV bool path_segment(PathState &ps, const SceneView &sc, const float *shade, float *lds,
                          unsigned long long *redo_count)
 {
-    const Hit h = closest_hit<FAST, false, KIND>(sc, ps.o, ps.d, lds, redo_count);
+    const Hit h = closest_hit<FAST, false, KIND, WAVE_SKIP>(sc, ps.o, ps.d, lds, redo_count);
     return shade_hit<FAST>(ps, sc, shade, h);
 }
 
@@ -425,7 +425,8 @@ PT_DEV void item_close(ItemState &it, float *slabs)
 // above MAX_LDS_SURFACES), SCENE_BVH when the scene has a hierarchy.
 // (At most 96 SGPRs, so that eight waves fit a SIMD: left alone the EXACT variant
 // takes 102 and runs seven, measured 3.8 % slower.)
-template <bool FAST, int KIND>
+// SPHERE_SKIP: the scan asks the wave before each sphere's square root (scan_surface).
+template <bool FAST, int KIND, bool SPHERE_SKIP = false>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96)))
 k_render_mega(RenderParams P)
 {
@@ -458,7 +459,7 @@ k_render_mega(RenderParams P)
             path_begin(ps, P.cam, it.pixel_key, it.s, it.px, it.py);
             need_path = false;
         }
-        const bool ended = path_segment<FAST, KIND>(ps, P.scene, shade, lds_shade, P.stats + 1);
+        const bool ended = path_segment<FAST, KIND, SPHERE_SKIP>(ps, P.scene, shade, lds_shade, P.stats + 1);
         n_seg++;
         if (ended) {
             it.sum = it.sum + ps.col;           // buffer[u][v] += color, main.cpp:139
