@@ -433,10 +433,11 @@ PT_DEV void scan_begin(Scan &st, V3 d)
 // be offered in ascending scene order (src/main.cpp:61 keeps the earlier one of
 // two equally distant hits).
 // WAVE_SKIP: before a sphere's square root, ask whether any lane of the wave
-// got past the reference's first two tests (tca >= 0, d2 <= radius2); if none
-// did, nothing can change.  Worth it when most waves miss most spheres (many
-// small ones: +16 % on the 79-sphere scene), a loss on a few large ones (-10 %
-// on cornell_2): the render kernel is compiled both ways and chosen by scene.
+// got past the reference's first two tests (tca >= 0, d2 <= radius2), and
+// before a triangle's v and t whether any lane can still be inside on u; if
+// none, nothing can change.  Worth it when most waves miss most surfaces (many
+// small ones), a loss on a few large ones: the render kernel is compiled both
+// ways and chosen by scene (pt_amd.hip, WAVE_SKIP_MIN_*).
 template <bool FAST, bool WAVE_SKIP = false>
 PT_DEV void scan_surface(Scan &st, int i, const GeomRec &rec, V3 o, V3 d)
 {
@@ -450,9 +451,15 @@ PT_DEV void scan_surface(Scan &st, int i, const GeomRec &rec, V3 o, V3 d)
         const TriDets q = triangle_dets_v<FAST>(v3(rec.q0.x, rec.q0.y, rec.q0.z), v3(rec.q1.x, rec.q1.y, rec.q1.z),
                                                 rec.q1.w, v3(rec.q2.x, rec.q2.y, rec.q2.z), o, st.nd);
         const float inv = __builtin_amdgcn_rcpf(q.det_a);
-        const float u = q.du * inv, v = q.dv * inv, t = q.dt * inv;
-        const float s = u + v;
+        const float u = q.du * inv;
         const bool det_bad = __builtin_fabsf(q.det_a) <= EPS_F;      // false for a NaN, as in the reference
+        if constexpr (WAVE_SKIP) {
+            // every lane surely outside on u alone (or parallel): v and t need not be formed
+            const bool out_on_u = det_bad | (u < BAND_LO_REJ) | (u > BAND_ONE_REJ);
+            if (!__any(!out_on_u)) return;
+        }
+        const float v = q.dv * inv, t = q.dt * inv;
+        const float s = u + v;
         const float dist = t * len_d;
         // non-short-circuit on purpose: every comparison is one instruction
         if constexpr (FAST) {

@@ -425,7 +425,7 @@ PT_DEV void item_close(ItemState &it, float *slabs)
 // above MAX_LDS_SURFACES), SCENE_BVH when the scene has a hierarchy.
 // (At most 96 SGPRs, so that eight waves fit a SIMD: left alone the EXACT variant
 // takes 102 and runs seven, measured 3.8 % slower.)
-// SPHERE_SKIP: the scan asks the wave before each sphere's square root (scan_surface).
+// SPHERE_SKIP: the scan's wave-level early-outs (scan_surface's WAVE_SKIP).
 template <bool FAST, int KIND, bool SPHERE_SKIP = false>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96)))
 k_render_mega(RenderParams P)
