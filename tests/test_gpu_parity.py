@@ -767,3 +767,24 @@ def test_soak_of_random_scenes_short():
                        capture_output=True, text=True, timeout=280)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     assert "360000 rays x 3 modes, 0 mismatches" in p.stdout
+
+
+def test_scan_with_wave_level_early_outs_renders_like_the_oracle(ctx, pt, orc):
+    """249 surfaces: below the hierarchy's threshold, above the one at which the render kernel
+    asks the whole wave before finishing a surface's test; also bit-identical to the same
+    scene rendered through the hierarchy."""
+    sc = pt.builtin_scene("heightfield:11", 120, 90)
+    assert len(sc.surfaces) == 2 * 11 * 11 + 7
+    osc = as_oracle_scene(orc, sc)
+    acc, cnt = render(ctx, pt, sc, 6, seed=12)
+    assert cnt.accel == pt.ACCEL_NONE
+    oacc, ocnt = orc.render(osc, 6, seed=12, threads=8)
+    frac = np.isclose(acc, oacc, rtol=2e-3, atol=2e-3).all(axis=2).mean()
+    assert frac >= 0.97 and abs(cnt.segments - ocnt.segments) <= 0.01 * ocnt.segments
+    try:
+        ctx.set_accel(pt.ACCEL_BVH)
+        via_bvh, bcnt = render(ctx, pt, sc, 6, seed=12)
+        assert bcnt.accel == pt.ACCEL_BVH and bcnt.segments == cnt.segments
+        assert np.array_equal(via_bvh, acc)
+    finally:
+        ctx.set_accel(pt.ACCEL_AUTO)
