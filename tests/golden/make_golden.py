@@ -3,8 +3,8 @@
 The reference ships no fixtures for this path and cannot be built in this
 image, so these vectors pin the ORACLE (oracle/pt_oracle.c), not the reference:
 they guard the oracle against regressions and give the GPU tests fixed inputs.
-The 14 known answers in survey_known_answers.json were recorded from the
-reference's own intersection code during the survey of the reference; the
+The 14 known answers in reference_known_answers.json were recorded from the
+reference's own intersection code when the reference was studied for this build; the
 oracle reproduces them bit for bit (tests/test_oracle.py).
 
 Run from the repository root:  python tests/golden/make_golden.py

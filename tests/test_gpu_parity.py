@@ -37,8 +37,8 @@ def test_primary_hits_bit_exact_vs_golden_800(ctx, pt, golden, name):
     assert np.array_equal(dist[::8, ::8], g[name + "_dist"])
 
 
-def test_survey_known_answers_on_gpu(ctx, pt):
-    with open(os.path.join(GOLDEN, "survey_known_answers.json")) as f:
+def test_reference_known_answers_on_gpu(ctx, pt):
+    with open(os.path.join(GOLDEN, "reference_known_answers.json")) as f:
         kat = json.load(f)
     for name, rows in kat.items():
         if name == "note":

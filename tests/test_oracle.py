@@ -1,4 +1,4 @@
-"""CPU tests of the oracle itself: the survey's known answers, the committed
+"""CPU tests of the oracle itself: the known answers recorded from the reference, the committed
 golden vectors, and properties of the restated algorithm."""
 import json
 import os
@@ -11,9 +11,9 @@ from conftest import GOLDEN
 SIZE = 800
 
 
-def test_survey_known_answers(orc):
+def test_reference_known_answers(orc):
     """14 primary-hit answers recorded from the reference's own intersection code."""
-    with open(os.path.join(GOLDEN, "survey_known_answers.json")) as f:
+    with open(os.path.join(GOLDEN, "reference_known_answers.json")) as f:
         kat = json.load(f)
     checked = 0
     for name, rows in kat.items():
