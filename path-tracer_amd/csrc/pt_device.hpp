@@ -588,7 +588,8 @@ PT_DEV V3 sample_diffuse(V3 normal, float u, float v)
     return dir;
 }
 
-// sample_mirror, src/material.hpp:29-31
+// sample_mirror, src/material.hpp:29-31.  (sample_pdf reaches the same direction through
+// sample_glass's reflection branch; this form documents what that branch must equal.)
 template <bool FAST>
 PT_DEV V3 sample_mirror(V3 normal, V3 incident)
 {
@@ -599,8 +600,12 @@ PT_DEV V3 sample_mirror(V3 normal, V3 incident)
 }
 
 // sample_glass, src/material.hpp:33-67
+// With mirror = true the reflectance is taken as 1: the reflected direction
+// i + 2 cosI n' (n' = the normal turned against the ray) is sample_mirror's
+// i - 2 (n.i) n, bit for bit (the two differ by exact negations only), so a
+// wave whose lanes hit mirrors and glass runs one block instead of two.
 template <bool FAST>
-PT_DEV V3 sample_glass(V3 normal, V3 incident, float xi)
+PT_DEV V3 sample_glass(V3 normal, V3 incident, float xi, bool mirror = false)
 {
     using N = Num<FAST>;
     float n1 = 1.0f, n2 = 1.5f;
@@ -621,7 +626,7 @@ PT_DEV V3 sample_glass(V3 normal, V3 incident, float xi)
         const float rPar = N::div(n2 * cosI - n1 * cosT, n2 * cosI + n1 * cosT);
         reflectance = (rOrth * rOrth + rPar * rPar) / 2.0f;
     }
-    if (xi < reflectance) {
+    if (mirror | (xi < reflectance)) {
         const float k = 2.0f * cosI;
         return v3(N::mad(k, normal.x, incident.x), N::mad(k, normal.y, incident.y),
                   N::mad(k, normal.z, incident.z));
@@ -636,8 +641,7 @@ template <bool FAST>
 PT_DEV V3 sample_pdf(int type, V3 normal, V3 incident, float xi0, float xi1)
 {
     if (type == 0) return sample_diffuse<FAST>(normal, xi0, xi1);
-    if (type == 1) return sample_mirror<FAST>(normal, incident);
-    return sample_glass<FAST>(normal, incident, xi0);
+    return sample_glass<FAST>(normal, incident, xi0, type == 1);
 }
 
 // Material::brdf, src/material.hpp:89-96: diffuse 2*color*dot(reflected, normal)
