@@ -213,6 +213,10 @@ int build_hierarchy(pt_ctx *ctx, const pt_surface *surfaces, int n_surfaces)
     }
     const int n = (int)inside.size();
     if (n < 2) return PT_OK;
+    if (n > BVH_MAX_LEAVES) {
+        if (ctx->accel == PT_ACCEL_AUTO) return PT_OK;           // the scan has no such limit
+        return fail(ctx, PT_E_LIMIT, "%d triangles exceed the hierarchy's maximum of %d", n, BVH_MAX_LEAVES);
+    }
 
     // centroid bounds of the triangles that go in, for the Morton grid
     for (int k = 0; k < 3; k++) { cmin[k] = INFINITY; cmax[k] = -INFINITY; }

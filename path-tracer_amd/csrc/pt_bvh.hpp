@@ -16,6 +16,7 @@ namespace ptd {
 //   q[2] = (right min xyz, -)         q[3] = (right max xyz, -)
 // A child ref >= 0 is an internal node, < 0 is leaf ~ref (position in Morton order).
 constexpr int BVH_NODE_QUADS = 4;
+constexpr int BVH_MAX_LEAVES = 1 << 25;          // nodes + leaves, 64 bytes each, within 4 GiB
 constexpr float BVH_ORIGIN_ROUNDING = 8e-6f;     // of |o|: some 60 ulps
 // A leaf is one triangle: its geometry record (GEOM_STRIDE floats) with the
 // surface's index in scene order in element 3 (where a geometry record keeps the kind).
@@ -462,7 +463,9 @@ PT_DEV void bvh_fetch_issue(const float4 *records, uint32_t rec, char *lds_wave,
     typedef __attribute__((address_space(3))) void *lds_p;
     // quad_perm [K,K,K,K]: every lane of a quad gets the value of the quad's lane K
     const uint32_t r = (uint32_t)__builtin_amdgcn_mov_dpp((int)rec, K * 0x55, 0xf, 0xf, true);
-    const float4 *src = records + (size_t)r * BVH_NODE_QUADS + quarter;
+    // a 32-bit byte offset from the (scalar) base: the hierarchy holds at most BVH_MAX_LEAVES
+    const uint32_t offset = r * (uint32_t)(BVH_NODE_QUADS * sizeof(float4)) + quarter * (uint32_t)sizeof(float4);
+    const char *src = reinterpret_cast<const char *>(records) + offset;
     __builtin_amdgcn_global_load_lds((global_p)(uintptr_t)src, (lds_p)(uintptr_t)(lds_wave + K * BVH_FETCH_SLAB), 16, 0, 0);
 }
 
