@@ -308,18 +308,22 @@ PT_DEV bool triangle_direct(cfloat_p g, V3 o, V3 d, V3 nd, float &t_out, float &
 // root: tca, and arg = radius2 - d2.  pre_ok is false when the reference has
 // already returned (tca < 0 or d2 > radius2).
 template <bool FAST>
-PT_DEV bool sphere_pre_v(V3 c, float radius2, V3 o, V3 d, float &tca, float &arg)
+PT_DEV void sphere_pre_terms(V3 c, float radius2, V3 o, V3 d, float &tca, float &d2, float &arg)
 {
     using N = Num<FAST>;
     const V3 L = c - o;
     tca = N::dot(L, d);
-    bool ok = !(tca < 0.0f);                                        // :94
-    float d2;
     if constexpr (FAST) d2 = __builtin_fmaf(-tca, tca, N::dot(L, L));
     else d2 = N::dot(L, L) - tca * tca;                             // :97
-    ok = ok && !(d2 > radius2);                                     // :98
     arg = radius2 - d2;
-    return ok;
+}
+
+template <bool FAST>
+PT_DEV bool sphere_pre_v(V3 c, float radius2, V3 o, V3 d, float &tca, float &arg)
+{
+    float d2;
+    sphere_pre_terms<FAST>(c, radius2, o, d, tca, d2, arg);
+    return !(tca < 0.0f) && !(d2 > radius2);                        // :94, :98
 }
 
 template <bool FAST>
@@ -410,9 +414,17 @@ constexpr float TRI_DIST_ERR = 2e-6f, SPH_DIST_ERR = 4e-7f;
 // sphere, t = a + sqrt(b).  code < 0: no hit yet.
 struct Best { int code; float lo, hi, a, b; };
 
-// A closest-hit scan in progress: the best candidate so far and whether any
-// decision taken for this lane fell inside an error band.
-struct Scan { Best best; bool unsure; V3 nd; float len_d; };
+// A closest-hit scan in progress: the best candidate so far and, as a wave mask
+// (one bit per lane, kept in scalar registers: no vector instruction per surface
+// to accumulate it), whether every decision taken for a lane so far fell outside
+// the error bands.  All lanes that want a result must run the scan together.
+// (Scalar instructions issue at half the rate of vector ones on this GPU, and the
+// scan's loop has one for every two vector instructions: their count matters.)
+struct Scan { Best best; unsigned long long sure; V3 nd; float len_d; };
+
+// This lane must be evaluated directly / some running lane must.
+PT_DEV bool scan_unsure(const Scan &st) { return !__builtin_amdgcn_inverse_ballot_w64(st.sure); }
+PT_DEV bool scan_any_unsure(const Scan &st) { return (__builtin_amdgcn_ballot_w64(true) & ~st.sure) != 0; }
 
 template <bool FAST>
 PT_DEV void scan_begin(Scan &st, V3 d)
@@ -426,7 +438,7 @@ PT_DEV void scan_begin(Scan &st, V3 d)
     st.len_d = __builtin_amdgcn_sqrtf(Num<FAST>::dot(d, d));
     // distances are estimated as t * |d|: a direction whose squared length leaves the
     // normal range (or is not a number) gets no estimates, only the direct evaluation
-    st.unsure = !FAST && !(st.len_d >= 1e-18f && st.len_d <= 1e18f);
+    st.sure = FAST ? ~0ull : __builtin_amdgcn_ballot_w64(st.len_d >= 1e-18f) & __builtin_amdgcn_ballot_w64(st.len_d <= 1e18f);
 }
 
 // One surface against the ray: i = its index in scene order.  Surfaces must
@@ -441,10 +453,17 @@ PT_DEV void scan_begin(Scan &st, V3 d)
 template <bool FAST, bool WAVE_SKIP = false>
 PT_DEV void scan_surface(Scan &st, int i, const GeomRec &rec, V3 o, V3 d)
 {
+    // Decisions are kept as wave masks (ballots of single comparisons, combined with
+    // scalar logic): the compiler then holds them in scalar registers across the
+    // triangle / sphere branch and the accumulation of `unsure` costs no vector work.
+    // A lane that is not running has 0 in every ballot; complements are only used
+    // under an AND with a ballot or with the mask of running lanes.
+    typedef unsigned long long Mask;
+#define PT_B(x) __builtin_amdgcn_ballot_w64(x)
     Best &best = st.best;
     const float len_d = st.len_d;
-    bool acc;           // surely a hit (FAST: a hit)
-    bool rej;           // surely not a hit
+    Mask acc;           // surely a hit (FAST: not used)
+    Mask rej;           // surely not a hit (FAST: not a hit)
     int mode;
     float c_lo, c_hi, a, b;
     if (rec.kind == GEOM_TRIANGLE) {             // wave-uniform branch
@@ -452,26 +471,25 @@ PT_DEV void scan_surface(Scan &st, int i, const GeomRec &rec, V3 o, V3 d)
                                                 rec.q1.w, v3(rec.q2.x, rec.q2.y, rec.q2.z), o, st.nd);
         const float inv = __builtin_amdgcn_rcpf(q.det_a);
         const float u = q.du * inv;
-        const bool det_bad = __builtin_fabsf(q.det_a) <= EPS_F;      // false for a NaN, as in the reference
+        const Mask det_bad = PT_B(__builtin_fabsf(q.det_a) <= EPS_F);      // false for a NaN, as in the reference
         if constexpr (WAVE_SKIP) {
             // every lane surely outside on u alone (or parallel): v and t need not be formed
-            const bool out_on_u = det_bad | (u < BAND_LO_REJ) | (u > BAND_ONE_REJ);
-            if (!__any(!out_on_u)) return;
+            const Mask out_on_u = det_bad | PT_B(u < BAND_LO_REJ) | PT_B(u > BAND_ONE_REJ);
+            if ((PT_B(true) & ~out_on_u) == 0) return;
         }
         const float v = q.dv * inv, t = q.dt * inv;
         const float s = u + v;
         const float dist = t * len_d;
-        // non-short-circuit on purpose: every comparison is one instruction
         if constexpr (FAST) {
-            acc = !(det_bad | (u < -EPS_F) | (u >= 1.0f) | (v < -EPS_F) | (s >= 1.0f) | (t <= EPS_F));
-            rej = !acc;
+            rej = det_bad | PT_B(u < -EPS_F) | PT_B(u >= 1.0f) | PT_B(v < -EPS_F) | PT_B(s >= 1.0f) | PT_B(t <= EPS_F);
+            acc = ~rej;
             c_lo = c_hi = dist;
         } else {
             // min/max drop a NaN operand; a NaN in u or v still fails s < BAND_ONE_ACC,
             // so it can make neither acc nor (alone) rej true and the lane is redone
             const float low_uv = __builtin_fminf(u, v);
-            rej = det_bad | (low_uv < BAND_LO_REJ) | (__builtin_fmaxf(u, s) > BAND_ONE_REJ) | (t < BAND_T_REJ);
-            acc = !det_bad & (low_uv > BAND_LO_ACC) & (u < BAND_ONE_ACC) & (s < BAND_ONE_ACC) & (t > BAND_T_ACC);
+            rej = det_bad | PT_B(low_uv < BAND_LO_REJ) | PT_B(__builtin_fmaxf(u, s) > BAND_ONE_REJ) | PT_B(t < BAND_T_REJ);
+            acc = ~det_bad & PT_B(low_uv > BAND_LO_ACC) & PT_B(u < BAND_ONE_ACC) & PT_B(s < BAND_ONE_ACC) & PT_B(t > BAND_T_ACC);
             c_lo = dist * (1.0f - TRI_DIST_ERR);
             c_hi = dist * (1.0f + TRI_DIST_ERR);
         }
@@ -479,42 +497,50 @@ PT_DEV void scan_surface(Scan &st, int i, const GeomRec &rec, V3 o, V3 d)
         a = q.dt;
         b = q.det_a;
     } else {
-        float tca, arg;
-        const bool pre_ok = sphere_pre_v<FAST>(v3(rec.q0.x, rec.q0.y, rec.q0.z), rec.q1.x, o, d, tca, arg);
+        float tca, d2, arg;
+        sphere_pre_terms<FAST>(v3(rec.q0.x, rec.q0.y, rec.q0.z), rec.q1.x, o, d, tca, d2, arg);
+        const Mask pre_ok = PT_B(true) & ~(PT_B(tca < 0.0f) | PT_B(d2 > rec.q1.x));     // surface.hpp:94, :98
         if constexpr (WAVE_SKIP) {
-            if (!__any(pre_ok)) return;
+            if (pre_ok == 0) return;
         }
         const float thc = __builtin_amdgcn_sqrtf(arg);
         const float t1 = tca - thc, t2 = tca + thc;
         if constexpr (FAST) {
             const bool near = !(t1 <= EPS_F);
             c_lo = c_hi = near ? t1 : t2;
-            acc = pre_ok & !(c_lo <= EPS_F);
-            rej = !acc;
+            rej = ~pre_ok | PT_B(c_lo <= EPS_F);
+            acc = ~rej;
             mode = near ? 1 : 2;
         } else {
             const float e1 = SPH_DIST_ERR * (thc + __builtin_fabsf(t1));
             const float e2 = SPH_DIST_ERR * (thc + __builtin_fabsf(t2));
             const float lo1 = t1 - e1, hi1 = t1 + e1, lo2 = t2 - e2, hi2 = t2 + e2;
-            const bool near_ok = lo1 > BAND_T_ACC, near_bad = hi1 < BAND_T_REJ;
-            const bool far_ok = lo2 > BAND_T_ACC, far_bad = hi2 < BAND_T_REJ;
+            const bool near_ok_lane = lo1 > BAND_T_ACC;
+            const Mask near_ok = PT_B(near_ok_lane), near_bad = PT_B(hi1 < BAND_T_REJ);
+            const Mask far_ok = PT_B(lo2 > BAND_T_ACC), far_bad = PT_B(hi2 < BAND_T_REJ);
             acc = pre_ok & (near_ok | (near_bad & far_ok));
-            rej = !pre_ok | (near_bad & far_bad);
-            c_lo = near_ok ? lo1 : lo2;
-            c_hi = near_ok ? hi1 : hi2;
-            mode = near_ok ? 1 : 2;
+            rej = ~pre_ok | (near_bad & far_bad);
+            c_lo = near_ok_lane ? lo1 : lo2;
+            c_hi = near_ok_lane ? hi1 : hi2;
+            mode = near_ok_lane ? 1 : 2;
         }
         a = tca;
         b = arg;
     }
     // src/main.cpp:61: a later surface replaces the current one only when strictly closer;
     // a candidate that is not a hit never wins and never ties
-    const bool closer = acc & !(c_hi >= best.lo);
-    if constexpr (!FAST) {
-        const bool not_closer = !acc | (c_lo >= best.hi);
-        st.unsure = st.unsure | !(acc | rej) | !(closer | not_closer);
+    const Mask maybe_farther = PT_B(c_hi >= best.lo);
+    Mask closer;
+    if constexpr (FAST) {
+        closer = ~(rej | maybe_farther);        // bits of lanes that are not running are never looked at
+    } else {
+        closer = acc & ~maybe_farther;
+        const Mask surely_farther = PT_B(c_lo >= best.hi);
+        // decided: surely no hit, or a hit that is surely closer or surely not closer
+        st.sure &= rej | (acc & ~(maybe_farther & ~surely_farther));
     }
-    if (closer) best = {4 * i + mode, c_lo, c_hi, a, b};
+    if (__builtin_amdgcn_inverse_ballot_w64(closer)) best = {4 * i + mode, c_lo, c_hi, a, b};
+#undef PT_B
 }
 
 // The hit a finished scan found, with the reference's t (and distance).  Not
@@ -560,8 +586,8 @@ PT_DEV Hit closest_intersection(cfloat_p geom, int n_surfaces, V3 o, V3 d,
         scan_surface<FAST, WAVE_SKIP>(st, i, geom_load(geom + (size_t)i * GEOM_STRIDE), o, d);
     }
     if constexpr (!FAST) {
-        if (__any(st.unsure)) {                      // rare: redo those lanes directly
-            if (st.unsure) {
+        if (scan_any_unsure(st)) {                   // rare: redo those lanes directly
+            if (scan_unsure(st)) {
                 if (redo_count) atomicAdd(redo_count, 1ull);
                 return closest_direct<false>(geom, n_surfaces, o, d, index_map);
             }

@@ -159,7 +159,7 @@ PT_DEV Hit closest_hit_tiled(const SceneView &sc, V3 o, V3 d, float *tiles /* 2 
         }
     }
     if constexpr (!FAST) {
-        if (st.unsure) return closest_direct<false>(as_constant(sc.geom), n, o, d);
+        if (scan_unsure(st)) return closest_direct<false>(as_constant(sc.geom), n, o, d);
     }
     return scan_finish<FAST, true>(st, d);
 }

@@ -1,0 +1,72 @@
+// Measures how vector and scalar ALU instructions share a SIMD's issue slots on
+// this GPU: a loop of V independent v_mul_f32 and S independent s_add_u32 per
+// iteration, 8 waves per SIMD, timed for several (V, S).  Prints cycles per
+// iteration per SIMD (from the kernel's duration and the shader clock).
+//   hipcc --offload-arch=gfx950 -O2 -o issue_rates issue_rates.hip && ./issue_rates
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <int V, int S, int B>
+__global__ void __launch_bounds__(256) k_mix(float *out, int iters)
+{
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    unsigned s0 = blockIdx.x, s1 = s0 + 1, s2 = s0 + 2, s3 = s0 + 3;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int k = 0; k < V / 8; k++)
+            asm volatile("v_mul_f32 %0, 0x3f800001, %0\n v_mul_f32 %1, 0x3f800001, %1\n v_mul_f32 %2, 0x3f800001, %2\n v_mul_f32 %3, 0x3f800001, %3\n"
+                         "v_mul_f32 %4, 0x3f800001, %4\n v_mul_f32 %5, 0x3f800001, %5\n v_mul_f32 %6, 0x3f800001, %6\n v_mul_f32 %7, 0x3f800001, %7\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+#pragma unroll
+        for (int k = 0; k < S / 4; k++)
+            asm volatile("s_add_u32 %0, %0, 3\n s_add_u32 %1, %1, 5\n s_add_u32 %2, %2, 7\n s_add_u32 %3, %3, 9\n"
+                         : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : : "scc");
+#pragma unroll
+        for (int k = 0; k < B; k++)          // taken scalar branches
+            asm volatile("s_cmp_eq_u32 %0, %0\n s_cbranch_scc1 1f\n s_nop 0\n1:\n" : : "s"(s0) : "scc");
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(s0 + s1 + s2 + s3);
+}
+
+template <int V, int S, int B>
+void run(float *out, int waves_per_simd, double mhz, int cus)
+{
+    const int iters = 20000;
+    const int blocks = cus * waves_per_simd;            // 256 threads = 4 waves = one per SIMD
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    k_mix<V, S, B><<<blocks, 256>>>(out, 100);
+    CHECK(hipEventRecord(e0));
+    k_mix<V, S, B><<<blocks, 256>>>(out, iters);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double cycles = ms * 1e-3 * mhz * 1e6 / iters;     // per iteration, all waves of a SIMD
+    printf("V=%3d S=%3d B=%d waves/SIMD=%d: %8.1f cycles/iteration/SIMD  (%.2f per wave-iteration; V alone would be %d, at 2 cycles each)\n",
+           V, S, B, waves_per_simd, cycles, cycles / waves_per_simd, 2 * V);
+}
+
+int main()
+{
+    hipDeviceProp_t p;
+    CHECK(hipGetDeviceProperties(&p, 0));
+    const double mhz = p.clockRate / 1000.0;
+    printf("%s, %d CUs, %.0f MHz\n", p.name, p.multiProcessorCount, mhz);
+    float *out;
+    CHECK(hipMalloc(&out, (size_t)p.multiProcessorCount * 8 * 256 * sizeof(float)));
+    for (int w : {1, 2, 8}) {
+        run<64, 0, 0>(out, w, mhz, p.multiProcessorCount);
+        run<0, 64, 0>(out, w, mhz, p.multiProcessorCount);
+        run<64, 16, 0>(out, w, mhz, p.multiProcessorCount);
+        run<64, 32, 0>(out, w, mhz, p.multiProcessorCount);
+        run<64, 64, 0>(out, w, mhz, p.multiProcessorCount);
+        run<64, 0, 4>(out, w, mhz, p.multiProcessorCount);
+        run<0, 0, 8>(out, w, mhz, p.multiProcessorCount);
+    }
+    CHECK(hipFree(out));
+    return 0;
+}
