@@ -707,6 +707,12 @@ static int set_scene_body(pt_ctx *ctx, const pt_surface *surfaces, int32_t n_sur
         memcpy(sh + 4, m.emittance, 12);
     }
 
+    // run lengths by kind, for the scan of the whole scene
+    for (int i = n_surfaces - 1, run = 0; i >= 0; i--) {
+        run = (i + 1 < n_surfaces && surfaces[i + 1].kind == surfaces[i].kind) ? run + 1 : 1;
+        memcpy(&geom[(size_t)i * GEOM_STRIDE + GEOM_RUN], &run, 4);
+    }
+
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_geom) (void)hipFree(ctx->d_geom);
     if (ctx->d_shade) (void)hipFree(ctx->d_shade);

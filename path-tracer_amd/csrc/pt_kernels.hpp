@@ -387,15 +387,15 @@ struct ItemState {
     V3 sum;
 };
 
-PT_DEV void item_open(ItemState &it, uint32_t item, const Camera &cam, uint32_t n_pixels, uint32_t first_sample,
+PT_DEV void item_open(ItemState &it, uint32_t item, int width, uint32_t n_pixels, uint32_t first_sample,
                       uint32_t spp, uint32_t chunk_len, uint32_t seed_mix)
 {
     it.item = item;
     it.have = true;
     const uint32_t chunk = item / n_pixels;
     it.pixel = item - chunk * n_pixels;
-    it.px = (int)(it.pixel % (uint32_t)cam.width);
-    it.py = (int)(it.pixel / (uint32_t)cam.width);
+    it.px = (int)(it.pixel % (uint32_t)width);
+    it.py = (int)(it.pixel / (uint32_t)width);
     it.s = first_sample + chunk * chunk_len;
     const uint32_t last = first_sample + spp;
     it.s_end = it.s + chunk_len < last ? it.s + chunk_len : last;
@@ -452,7 +452,7 @@ k_render_mega(RenderParams P)
             const uint32_t got = pool_take(pool, want, P.queue_head, P.n_items);
             if (want) {
                 if (got == NO_ITEM) break;      // queue empty: this lane retires
-                item_open(it, got, P.cam, P.n_pixels, P.first_sample, P.spp, P.chunk_len, P.seed_mix);
+                item_open(it, got, P.cam.width, P.n_pixels, P.first_sample, P.spp, P.chunk_len, P.seed_mix);
             }
         }
         if (need_path) {
@@ -528,7 +528,7 @@ k_render_mega_bvh(RenderParams P)
                 const uint32_t got = pool_take(pool, want, P.queue_head, P.n_items);
                 if (want) {
                     if (got == NO_ITEM) alive = false;       // queue empty: this lane retires
-                    else item_open(it, got, P.cam, P.n_pixels, P.first_sample, P.spp, P.chunk_len, P.seed_mix);
+                    else item_open(it, got, P.cam.width, P.n_pixels, P.first_sample, P.spp, P.chunk_len, P.seed_mix);
                 }
             }
             if (waits && alive) {
