@@ -241,7 +241,10 @@ PT_DEV TriDets triangle_dets_v(V3 v0, V3 e1, float m_e, V3 e2, V3 o, V3 nd)
     const float m_be2 = N::msub(b.y, e2.z, e2.y, b.z);
     const float m_db = N::msub(nd.y, b.z, b.y, nd.z);
     const float m_e1b = N::msub(e1.y, b.z, b.y, e1.z);
-    const float m_be1 = N::msub(b.y, e1.z, e1.y, b.z);
+    // b.y*e1.z - e1.y*b.z: the same two products subtracted the other way round, and
+    // rounding to nearest is symmetric, so this is exact (the negation folds into the
+    // instruction that uses it)
+    const float m_be1 = -m_e1b;
     TriDets r;
     if constexpr (FAST) {
         r.det_a = __builtin_fmaf(e2.x, m_de1, __builtin_fmaf(nd.x, m_e, -(e1.x * m_de2)));
