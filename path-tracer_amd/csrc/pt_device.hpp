@@ -437,6 +437,32 @@ constexpr float BAND_T_REJ = 0.99999e-5f, BAND_T_ACC = 1.00001e-5f;       // rou
 constexpr float BAND_ONE_REJ = 1.0f + 2e-6f, BAND_ONE_ACC = 1.0f - 2e-6f; // round 1
 constexpr float TRI_DIST_ERR = 2e-6f, SPH_DIST_ERR = 4e-7f;
 
+// Lanes whose x compares with the constant K as named, as a wave mask.  The
+// constant travels in the instruction: measured on this GPU (tools/micro), a
+// vector instruction with a scalar-register operand issues at little more than
+// half the rate of one with a literal or vector-register operand, and left alone
+// the compiler keeps such thresholds in scalar registers.  (The compare writes
+// VCC, the only destination the encoding with a literal has.)
+typedef unsigned long long LaneMask;
+constexpr uint32_t f32_bits(float x) { return __builtin_bit_cast(uint32_t, x); }
+// NAME<K>(m, x) = m OP lanes(x CMP K); the compare is written with K as its first operand.
+#define PT_LANES_FN(NAME, VCMP, SOP, OPERANDS)                                                                  \
+    template <uint32_t K> PT_DEV LaneMask NAME(LaneMask m, float x)                                              \
+    {                                                                                                            \
+        LaneMask r;                                                                                              \
+        asm("v_cmp_" VCMP "_f32 vcc, %2, %3\n\ts_" SOP "_b64 %0, " OPERANDS : "=s"(r) : "s"(m), "n"(K), "v"(x) : "vcc"); \
+        return r;                                                                                                \
+    }
+PT_LANES_FN(or_lt, "gt", "or", "%1, vcc")          // m | (x < K)
+PT_LANES_FN(or_gt, "lt", "or", "%1, vcc")          // m | (x > K)
+PT_LANES_FN(or_le, "ge", "or", "%1, vcc")          // m | (x <= K)
+PT_LANES_FN(and_lt, "gt", "and", "%1, vcc")        // m & (x < K)
+PT_LANES_FN(and_gt, "lt", "and", "%1, vcc")        // m & (x > K)
+PT_LANES_FN(gt_andn, "lt", "andn2", "vcc, %1")     // (x > K) & ~m
+#undef PT_LANES_FN
+template <uint32_t K> PT_DEV LaneMask lanes_lt(float x) { return or_lt<K>(0ull, x); }
+template <uint32_t K> PT_DEV LaneMask lanes_gt(float x) { return or_gt<K>(0ull, x); }
+
 // Best candidate so far.  [lo, hi] brackets its exact distance; a and b are the
 // exact operands of the final evaluation; code = 4 * surface index + mode, with
 // mode 0: triangle, t = a / b;  mode 1: sphere, t = a - sqrt(b);  mode 2:
@@ -504,22 +530,28 @@ PT_DEV void scan_surface(Scan &st, int i, const GeomRec &rec, V3 o, V3 d)
         const Mask det_bad = PT_B(__builtin_fabsf(q.det_a) <= EPS_F);      // false for a NaN, as in the reference
         if constexpr (WAVE_SKIP) {
             // every lane surely outside on u alone (or parallel): v and t need not be formed
-            const Mask out_on_u = det_bad | PT_B(u < BAND_LO_REJ) | PT_B(u > BAND_ONE_REJ);
+            const Mask out_on_u = or_gt<f32_bits(BAND_ONE_REJ)>(or_lt<f32_bits(BAND_LO_REJ)>(det_bad, u), u);
             if ((PT_B(true) & ~out_on_u) == 0) return;
         }
         const float v = q.dv * inv, t = q.dt * inv;
         const float s = u + v;
         const float dist = t * len_d;
         if constexpr (FAST) {
-            rej = det_bad | PT_B(u < -EPS_F) | PT_B(u >= 1.0f) | PT_B(v < -EPS_F) | PT_B(s >= 1.0f) | PT_B(t <= EPS_F);
+            rej = det_bad | PT_B(u >= 1.0f) | PT_B(s >= 1.0f);
+            rej = or_le<f32_bits(EPS_F)>(or_lt<f32_bits(-EPS_F)>(or_lt<f32_bits(-EPS_F)>(rej, u), v), t);
             acc = ~rej;
             c_lo = c_hi = dist;
         } else {
             // min/max drop a NaN operand; a NaN in u or v still fails s < BAND_ONE_ACC,
             // so it can make neither acc nor (alone) rej true and the lane is redone
             const float low_uv = __builtin_fminf(u, v);
-            rej = det_bad | PT_B(low_uv < BAND_LO_REJ) | PT_B(__builtin_fmaxf(u, s) > BAND_ONE_REJ) | PT_B(t < BAND_T_REJ);
-            acc = ~det_bad & PT_B(low_uv > BAND_LO_ACC) & PT_B(u < BAND_ONE_ACC) & PT_B(s < BAND_ONE_ACC) & PT_B(t > BAND_T_ACC);
+            rej = or_lt<f32_bits(BAND_LO_REJ)>(det_bad, low_uv);
+            rej = or_gt<f32_bits(BAND_ONE_REJ)>(rej, __builtin_fmaxf(u, s));
+            rej = or_lt<f32_bits(BAND_T_REJ)>(rej, t);
+            acc = gt_andn<f32_bits(BAND_LO_ACC)>(det_bad, low_uv);
+            acc = and_lt<f32_bits(BAND_ONE_ACC)>(acc, u);
+            acc = and_lt<f32_bits(BAND_ONE_ACC)>(acc, s);
+            acc = and_gt<f32_bits(BAND_T_ACC)>(acc, t);
             c_lo = dist * (1.0f - TRI_DIST_ERR);
             c_hi = dist * (1.0f + TRI_DIST_ERR);
         }
@@ -538,13 +570,15 @@ PT_DEV void scan_surface(Scan &st, int i, const GeomRec &rec, V3 o, V3 d)
         if constexpr (FAST) {
             const bool near = !(t1 <= EPS_F);
             c_lo = c_hi = near ? t1 : t2;
-            rej = ~pre_ok | PT_B(c_lo <= EPS_F);
+            rej = or_le<f32_bits(EPS_F)>(~pre_ok, c_lo);
             acc = ~rej;
             mode = near ? 1 : 2;
         } else {
             const float e1 = SPH_DIST_ERR * (thc + __builtin_fabsf(t1));
             const float e2 = SPH_DIST_ERR * (thc + __builtin_fabsf(t2));
             const float lo1 = t1 - e1, hi1 = t1 + e1, lo2 = t2 - e2, hi2 = t2 + e2;
+            // (compares that start a mask of their own: the literal form needs a scalar move
+            // each, measured no better than the compiler's scalar-register operands)
             const bool near_ok_lane = lo1 > BAND_T_ACC;
             const Mask near_ok = PT_B(near_ok_lane), near_bad = PT_B(hi1 < BAND_T_REJ);
             const Mask far_ok = PT_B(lo2 > BAND_T_ACC), far_bad = PT_B(hi2 < BAND_T_REJ);

@@ -9,6 +9,71 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
+// FORM 0: v_mul_f32 with a 32-bit literal (8-byte encoding); 1: v_mul_f32 of two registers
+// (4 bytes); 2: v_fma_f32 of three registers (8 bytes).
+template <int FORM>
+__global__ void __launch_bounds__(256) k_valu(float *out, int iters)
+{
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    float c = 1.0000001f, c2 = 1e-9f, sc = 1.0000001f;
+    asm volatile("" : "+v"(c), "+v"(c2), "+s"(sc));
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (FORM == 0)
+                asm volatile("v_mul_f32 %0, 0x3f800001, %0\n v_mul_f32 %1, 0x3f800001, %1\n v_mul_f32 %2, 0x3f800001, %2\n v_mul_f32 %3, 0x3f800001, %3\n"
+                             "v_mul_f32 %4, 0x3f800001, %4\n v_mul_f32 %5, 0x3f800001, %5\n v_mul_f32 %6, 0x3f800001, %6\n v_mul_f32 %7, 0x3f800001, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            else if (FORM == 1)
+                asm volatile("v_mul_f32 %0, %8, %0\n v_mul_f32 %1, %8, %1\n v_mul_f32 %2, %8, %2\n v_mul_f32 %3, %8, %3\n"
+                             "v_mul_f32 %4, %8, %4\n v_mul_f32 %5, %8, %5\n v_mul_f32 %6, %8, %6\n v_mul_f32 %7, %8, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
+            else if (FORM == 3)      // distinct multiplier and addend registers
+                asm volatile("v_fma_f32 %0, %8, %0, %9\n v_fma_f32 %1, %8, %1, %9\n v_fma_f32 %2, %8, %2, %9\n v_fma_f32 %3, %8, %3, %9\n"
+                             "v_fma_f32 %4, %8, %4, %9\n v_fma_f32 %5, %8, %5, %9\n v_fma_f32 %6, %8, %6, %9\n v_fma_f32 %7, %8, %7, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(c2));
+            else if (FORM == 4)      // multiplier in a scalar register
+                asm volatile("v_fma_f32 %0, %8, %0, %9\n v_fma_f32 %1, %8, %1, %9\n v_fma_f32 %2, %8, %2, %9\n v_fma_f32 %3, %8, %3, %9\n"
+                             "v_fma_f32 %4, %8, %4, %9\n v_fma_f32 %5, %8, %5, %9\n v_fma_f32 %6, %8, %6, %9\n v_fma_f32 %7, %8, %7, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(sc), "v"(c2));
+            else if (FORM == 5)      // v_fmac_f32: accumulate into the destination (4-byte encoding)
+                asm volatile("v_fmac_f32 %0, %8, %9\n v_fmac_f32 %1, %8, %9\n v_fmac_f32 %2, %8, %9\n v_fmac_f32 %3, %8, %9\n"
+                             "v_fmac_f32 %4, %8, %9\n v_fmac_f32 %5, %8, %9\n v_fmac_f32 %6, %8, %9\n v_fmac_f32 %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(c2));
+            else if (FORM == 6)      // v_add_f32 of two registers
+                asm volatile("v_add_f32 %0, %8, %0\n v_add_f32 %1, %8, %1\n v_add_f32 %2, %8, %2\n v_add_f32 %3, %8, %3\n"
+                             "v_add_f32 %4, %8, %4\n v_add_f32 %5, %8, %5\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
+            else if (FORM == 7)      // v_mul_f32 with a scalar register operand
+                asm volatile("v_mul_f32 %0, %8, %0\n v_mul_f32 %1, %8, %1\n v_mul_f32 %2, %8, %2\n v_mul_f32 %3, %8, %3\n"
+                             "v_mul_f32 %4, %8, %4\n v_mul_f32 %5, %8, %5\n v_mul_f32 %6, %8, %6\n v_mul_f32 %7, %8, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(sc));
+            else
+                asm volatile("v_fma_f32 %0, %8, %0, %8\n v_fma_f32 %1, %8, %1, %8\n v_fma_f32 %2, %8, %2, %8\n v_fma_f32 %3, %8, %3, %8\n"
+                             "v_fma_f32 %4, %8, %4, %8\n v_fma_f32 %5, %8, %5, %8\n v_fma_f32 %6, %8, %6, %8\n v_fma_f32 %7, %8, %7, %8\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
+template <int FORM>
+void run_valu(float *out, int waves_per_simd, double mhz, int cus)
+{
+    const int iters = 20000;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    k_valu<FORM><<<cus * waves_per_simd, 256>>>(out, 100);
+    CHECK(hipEventRecord(e0));
+    k_valu<FORM><<<cus * waves_per_simd, 256>>>(out, iters);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    printf("form %d, waves/SIMD=%d: %.3f cycles per vector instruction per SIMD (at the nominal clock)\n", FORM, waves_per_simd,
+           ms * 1e-3 * mhz * 1e6 / iters / (64.0 * waves_per_simd));
+}
+
 template <int V, int S, int B>
 __global__ void __launch_bounds__(256) k_mix(float *out, int iters)
 {
@@ -58,6 +123,16 @@ int main()
     printf("%s, %d CUs, %.0f MHz\n", p.name, p.multiProcessorCount, mhz);
     float *out;
     CHECK(hipMalloc(&out, (size_t)p.multiProcessorCount * 8 * 256 * sizeof(float)));
+    for (int w : {1, 8}) {
+        run_valu<0>(out, w, mhz, p.multiProcessorCount);
+        run_valu<1>(out, w, mhz, p.multiProcessorCount);
+        run_valu<2>(out, w, mhz, p.multiProcessorCount);
+        run_valu<3>(out, w, mhz, p.multiProcessorCount);
+        run_valu<4>(out, w, mhz, p.multiProcessorCount);
+        run_valu<5>(out, w, mhz, p.multiProcessorCount);
+        run_valu<6>(out, w, mhz, p.multiProcessorCount);
+        run_valu<7>(out, w, mhz, p.multiProcessorCount);
+    }
     for (int w : {1, 2, 8}) {
         run<64, 0, 0>(out, w, mhz, p.multiProcessorCount);
         run<0, 64, 0>(out, w, mhz, p.multiProcessorCount);
