@@ -788,3 +788,31 @@ def test_scan_with_wave_level_early_outs_renders_like_the_oracle(ctx, pt, orc):
         assert np.array_equal(via_bvh, acc)
     finally:
         ctx.set_accel(pt.ACCEL_AUTO)
+
+
+def test_scan_by_runs_of_one_kind_on_interleaved_kinds(ctx, pt, orc):
+    """Spheres and triangles shuffled together (runs of one kind one to a few surfaces long,
+    enough of both kinds for the render kernel that scans run by run with wave-level
+    early-outs): the same paths as the wavefront layout, which scans surface by surface, and
+    the oracle's image."""
+    a = pt.builtin_scene("glass_stress", 96, 64)
+    b = pt.builtin_scene("heightfield:5", 96, 64)
+    surf = np.concatenate([a.surfaces, b.surfaces])
+    surf["material"][len(a.surfaces):] += len(a.materials)
+    mats = np.concatenate([a.materials, b.materials])
+    surf = surf[np.random.default_rng(21).permutation(len(surf))]
+    kinds = surf["kind"]
+    assert (kinds == pt.SPHERE).sum() >= 16 and (kinds == pt.TRIANGLE).sum() >= 32
+    assert (np.diff(kinds) != 0).sum() > 40                     # many short runs
+    sc = pt.SceneData(surf, mats, a.bg, a.camera)
+    try:
+        ctx.set_accel(pt.ACCEL_NONE)
+        mega, cm = render(ctx, pt, sc, 6, first=2, seed=5, mode=pt.MODE_MEGAKERNEL)
+        wave, cw = render(ctx, pt, sc, 6, first=2, seed=5, mode=pt.MODE_WAVEFRONT)
+    finally:
+        ctx.set_accel(pt.ACCEL_AUTO)
+    assert cm.accel == pt.ACCEL_NONE and cw.segments == cm.segments
+    assert np.allclose(wave, mega, rtol=1e-5, atol=1e-6)
+    oacc, ocnt = orc.render(as_oracle_scene(orc, sc), 6, first_sample=2, seed=5, threads=8)
+    frac = np.isclose(mega, oacc, rtol=2e-3, atol=2e-3).all(axis=2).mean()
+    assert frac >= 0.95 and abs(cm.segments - ocnt.segments) <= 0.01 * ocnt.segments
