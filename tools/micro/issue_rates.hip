@@ -9,6 +9,8 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
+__device__ long long g_cycles;
+
 // FORM 0: v_mul_f32 with a 32-bit literal (8-byte encoding); 1: v_mul_f32 of two registers
 // (4 bytes); 2: v_fma_f32 of three registers (8 bytes).
 template <int FORM>
@@ -17,6 +19,7 @@ __global__ void __launch_bounds__(256) k_valu(float *out, int iters)
     float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     float c = 1.0000001f, c2 = 1e-9f, sc = 1.0000001f;
     asm volatile("" : "+v"(c), "+v"(c2), "+s"(sc));
+    const long long t0 = clock64();
     for (int it = 0; it < iters; it++) {
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -55,6 +58,8 @@ __global__ void __launch_bounds__(256) k_valu(float *out, int iters)
         }
     }
     out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    // shader-clock cycles this wave spent in the loop (s_memtime), for the first wave of the grid
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_cycles = clock64() - t0;
 }
 
 template <int FORM>
@@ -70,8 +75,13 @@ void run_valu(float *out, int waves_per_simd, double mhz, int cus)
     CHECK(hipEventSynchronize(e1));
     float ms;
     CHECK(hipEventElapsedTime(&ms, e0, e1));
-    printf("form %d, waves/SIMD=%d: %.3f cycles per vector instruction per SIMD (at the nominal clock)\n", FORM, waves_per_simd,
+    long long cycles = 0;
+    CHECK(hipMemcpyFromSymbol(&cycles, HIP_SYMBOL(g_cycles), sizeof cycles));
+    printf("form %d, waves/SIMD=%d: %.3f cycles per vector instruction per SIMD at the nominal clock", FORM, waves_per_simd,
            ms * 1e-3 * mhz * 1e6 / iters / (64.0 * waves_per_simd));
+    // (with several waves the oldest one is served first and finishes early: its counter says nothing about the SIMD)
+    if (waves_per_simd == 1) printf(", %.3f by the wave's own cycle counter", (double)cycles / iters / 64.0);
+    printf("\n");
 }
 
 template <int V, int S, int B>
