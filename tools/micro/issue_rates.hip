@@ -18,7 +18,8 @@ __global__ void __launch_bounds__(256) k_valu(float *out, int iters)
 {
     float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     float c = 1.0000001f, c2 = 1e-9f, sc = 1.0000001f;
-    asm volatile("" : "+v"(c), "+v"(c2), "+s"(sc));
+    unsigned long long mask = 0x5555555555555555ull, mask2 = 0;
+    asm volatile("" : "+v"(c), "+v"(c2), "+s"(sc), "+s"(mask), "+s"(mask2));
     const long long t0 = clock64();
     for (int it = 0; it < iters; it++) {
 #pragma unroll
@@ -46,6 +47,42 @@ __global__ void __launch_bounds__(256) k_valu(float *out, int iters)
             else if (FORM == 6)      // v_add_f32 of two registers
                 asm volatile("v_add_f32 %0, %8, %0\n v_add_f32 %1, %8, %1\n v_add_f32 %2, %8, %2\n v_add_f32 %3, %8, %3\n"
                              "v_add_f32 %4, %8, %4\n v_add_f32 %5, %8, %5\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
+            else if (FORM == 8)      // v_mul_lo_u32 (32-bit integer multiply)
+                asm volatile("v_mul_lo_u32 %0, %8, %0\n v_mul_lo_u32 %1, %8, %1\n v_mul_lo_u32 %2, %8, %2\n v_mul_lo_u32 %3, %8, %3\n"
+                             "v_mul_lo_u32 %4, %8, %4\n v_mul_lo_u32 %5, %8, %5\n v_mul_lo_u32 %6, %8, %6\n v_mul_lo_u32 %7, %8, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
+            else if (FORM == 9)      // v_rcp_f32
+                asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n"
+                             "v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            else if (FORM == 10)     // v_mad_u32_u24
+                asm volatile("v_mad_u32_u24 %0, %8, %0, %8\n v_mad_u32_u24 %1, %8, %1, %8\n v_mad_u32_u24 %2, %8, %2, %8\n v_mad_u32_u24 %3, %8, %3, %8\n"
+                             "v_mad_u32_u24 %4, %8, %4, %8\n v_mad_u32_u24 %5, %8, %5, %8\n v_mad_u32_u24 %6, %8, %6, %8\n v_mad_u32_u24 %7, %8, %7, %8\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
+            else if (FORM == 11)     // v_cndmask_b32 with a mask in scalar registers
+                asm volatile("v_cndmask_b32 %0, %8, %0, %9\n v_cndmask_b32 %1, %8, %1, %9\n v_cndmask_b32 %2, %8, %2, %9\n v_cndmask_b32 %3, %8, %3, %9\n"
+                             "v_cndmask_b32 %4, %8, %4, %9\n v_cndmask_b32 %5, %8, %5, %9\n v_cndmask_b32 %6, %8, %6, %9\n v_cndmask_b32 %7, %8, %7, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "s"(mask));
+            else if (FORM == 12)     // v_cmp_lt_f32 into a scalar register pair
+                asm volatile("v_cmp_lt_f32 %10, %8, %0\n v_cmp_lt_f32 %10, %8, %1\n v_cmp_lt_f32 %10, %8, %2\n v_cmp_lt_f32 %10, %8, %3\n"
+                             "v_cmp_lt_f32 %10, %8, %4\n v_cmp_lt_f32 %10, %8, %5\n v_cmp_lt_f32 %10, %8, %6\n v_cmp_lt_f32 %10, %8, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "s"(mask), "s"(mask2));
+            else if (FORM == 13)     // v_cmp_lt_f32 into VCC, two vector registers (4-byte encoding)
+                asm volatile("v_cmp_lt_f32 vcc, %8, %0\n v_cmp_lt_f32 vcc, %8, %1\n v_cmp_lt_f32 vcc, %8, %2\n v_cmp_lt_f32 vcc, %8, %3\n"
+                             "v_cmp_lt_f32 vcc, %8, %4\n v_cmp_lt_f32 vcc, %8, %5\n v_cmp_lt_f32 vcc, %8, %6\n v_cmp_lt_f32 vcc, %8, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c) : "vcc");
+            else if (FORM == 14)     // v_cmp_lt_f32 into VCC, a literal and a vector register
+                asm volatile("v_cmp_lt_f32 vcc, 0x3f800011, %0\n v_cmp_lt_f32 vcc, 0x3f800011, %1\n v_cmp_lt_f32 vcc, 0x3f800011, %2\n v_cmp_lt_f32 vcc, 0x3f800011, %3\n"
+                             "v_cmp_lt_f32 vcc, 0x3f800011, %4\n v_cmp_lt_f32 vcc, 0x3f800011, %5\n v_cmp_lt_f32 vcc, 0x3f800011, %6\n v_cmp_lt_f32 vcc, 0x3f800011, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "vcc");
+            else if (FORM == 15)     // v_cndmask_b32 with the mask in VCC (4-byte encoding)
+                asm volatile("v_cndmask_b32 %0, %8, %0, vcc\n v_cndmask_b32 %1, %8, %1, vcc\n v_cndmask_b32 %2, %8, %2, vcc\n v_cndmask_b32 %3, %8, %3, vcc\n"
+                             "v_cndmask_b32 %4, %8, %4, vcc\n v_cndmask_b32 %5, %8, %5, vcc\n v_cndmask_b32 %6, %8, %6, vcc\n v_cndmask_b32 %7, %8, %7, vcc\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c) : "vcc");
+            else if (FORM == 16)     // v_sub_f32 with a negated-operand modifier (8-byte encoding), vector registers
+                asm volatile("v_mul_f32_e64 %0, %8, -%0\n v_mul_f32_e64 %1, %8, -%1\n v_mul_f32_e64 %2, %8, -%2\n v_mul_f32_e64 %3, %8, -%3\n"
+                             "v_mul_f32_e64 %4, %8, -%4\n v_mul_f32_e64 %5, %8, -%5\n v_mul_f32_e64 %6, %8, -%6\n v_mul_f32_e64 %7, %8, -%7\n"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
             else if (FORM == 7)      // v_mul_f32 with a scalar register operand
                 asm volatile("v_mul_f32 %0, %8, %0\n v_mul_f32 %1, %8, %1\n v_mul_f32 %2, %8, %2\n v_mul_f32 %3, %8, %3\n"
@@ -142,6 +179,15 @@ int main()
         run_valu<5>(out, w, mhz, p.multiProcessorCount);
         run_valu<6>(out, w, mhz, p.multiProcessorCount);
         run_valu<7>(out, w, mhz, p.multiProcessorCount);
+        run_valu<8>(out, w, mhz, p.multiProcessorCount);
+        run_valu<9>(out, w, mhz, p.multiProcessorCount);
+        run_valu<10>(out, w, mhz, p.multiProcessorCount);
+        run_valu<11>(out, w, mhz, p.multiProcessorCount);
+        run_valu<12>(out, w, mhz, p.multiProcessorCount);
+        run_valu<13>(out, w, mhz, p.multiProcessorCount);
+        run_valu<14>(out, w, mhz, p.multiProcessorCount);
+        run_valu<15>(out, w, mhz, p.multiProcessorCount);
+        run_valu<16>(out, w, mhz, p.multiProcessorCount);
     }
     for (int w : {1, 2, 8}) {
         run<64, 0, 0>(out, w, mhz, p.multiProcessorCount);
