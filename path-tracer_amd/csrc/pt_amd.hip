@@ -351,7 +351,12 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
         if (ctx->n_sph >= WAVE_SKIP_MIN_SPHERES || ctx->n_tri >= WAVE_SKIP_MIN_TRIANGLES)
             kernel = &k_render_mega<FAST, KIND, true>;
     }
-    if constexpr (KIND == SCENE_BVH) kernel = &k_render_mega_bvh<FAST>;
+    const double samples = (double)n_pixels * spp;
+    const int blocks_wanted = std::max(1, (int)std::lround(std::sqrt(samples / 3e5)));
+    if constexpr (KIND == SCENE_BVH) {
+        kernel = &k_render_mega_bvh<FAST>;
+        if (blocks_wanted >= 7) kernel = &k_render_mega_bvh<FAST, 7>;
+    }
     int blocks_per_cu = 0;
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, BLOCK, lds_bytes));
     if (blocks_per_cu < 1) return fail(ctx, PT_E_HIP, "render kernel does not fit on a compute unit");
@@ -360,8 +365,7 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
     // finish such a launch sooner.  Measured against launching all that fit:
     // 356x200 at 1 spp 244 -> 124 us (one workgroup per CU), 800x800 at 4 spp
     // 698 -> 609 us (three); from about 64 spp at 800x800 all that fit is fastest.
-    const double samples = (double)n_pixels * spp;
-    blocks_per_cu = std::min(blocks_per_cu, std::max(1, (int)std::lround(std::sqrt(samples / 3e5))));
+    blocks_per_cu = std::min(blocks_per_cu, blocks_wanted);
     const uint32_t grid = (uint32_t)blocks_per_cu * (uint32_t)ctx->num_cus;
     const uint64_t lanes = (uint64_t)grid * BLOCK;
 

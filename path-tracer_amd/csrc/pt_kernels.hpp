@@ -481,9 +481,12 @@ k_render_mega(RenderParams P)
 // (bvh_fetch_records), which needs all 64 lanes: a lane that finds the queue
 // empty stays in the loop, idle, until the whole wave is done.
 // (Held to 80 VGPRs, 6 waves per SIMD: left alone it takes 83 and runs 5, measured
-// 5 % slower; forced down to 64 VGPRs for 8 waves it spills, 9 % slower.)
-template <bool FAST>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6)))
+// 5 % slower; forced down to 64 VGPRs for 8 waves it spills, 9 % slower.  WAVES = 7,
+// 72 VGPRs, keeps eight loop-invariant values in scratch memory: 3.4 % faster on a
+// launch large enough to fill seven waves per SIMD, 4 % slower on one that is not;
+// the host picks by launch size.)
+template <bool FAST, int WAVES = 6>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 k_render_mega_bvh(RenderParams P)
 {
     __shared__ __align__(16) char fetch_lds[(BLOCK / 64) * BVH_FETCH_LDS];
