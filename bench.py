@@ -17,7 +17,8 @@ algorithmic flops = segments x (63 per triangle test + 18 per sphere test),
 every surface counted as tested for every segment, divided by the kernel's
 duration from HIP events recorded on the launch stream.  `cpu_baseline` times
 the CPU oracle (a port of the reference's serial loop) on a bounded sample of
-the same workload on this box's host, one thread.
+the same workload on this box's host, one thread (and, beside it as
+`all_cores`, with OpenMP over image columns on up to 16 threads).
 """
 import argparse
 import json
@@ -56,10 +57,22 @@ def cpu_baseline(scene_name, width, height, spp):
     t0 = time.perf_counter()
     _, cnt = pt_oracle.render(sc, spp, first_sample=0, seed=1, threads=1)
     dt = time.perf_counter() - t0
-    return {"value": width * height * spp / dt / 1e6, "unit": "Msamples/s", "cores": 1,
-            "kind": "port",
-            "sample": "%s %dx%d, %d spp (%.1f s, %.2f segments/sample)" % (
-                scene_name, width, height, spp, dt, cnt.segments / cnt.samples)}
+    out = {"value": width * height * spp / dt / 1e6, "unit": "Msamples/s", "cores": 1,
+           "kind": "port",
+           "sample": "%s %dx%d, %d spp (%.1f s, %.2f segments/sample)" % (
+               scene_name, width, height, spp, dt, cnt.segments / cnt.samples)}
+    # the same loop over columns with the OpenMP pragma the reference left commented out
+    # (src/main.cpp:117), on this process's share of the host's cores
+    share = len(os.sched_getaffinity(0))
+    threads = max(1, min(share, int(os.environ.get("OMP_NUM_THREADS", "16")), 16))
+    if threads > 1:
+        many = 2 * spp
+        t0 = time.perf_counter()
+        pt_oracle.render(sc, many, first_sample=0, seed=1, threads=threads)
+        dt = time.perf_counter() - t0
+        out["all_cores"] = {"value": width * height * many / dt / 1e6, "unit": "Msamples/s", "cores": threads,
+                            "sample": "%d spp (%.1f s)" % (many, dt)}
+    return out
 
 
 def intersection_kernel(pt_amd, scene_name, device):
