@@ -216,6 +216,10 @@ def main():
             "vgprs": int(c.vgprs),
             "grid_blocks": int(c.grid_blocks),
         }
+        if args.layout == "megakernel":
+            # persistent workgroups of four waves, one per SIMD: workgroups per CU = waves per SIMD
+            cus = torch.cuda.get_device_properties(device).multi_processor_count
+            out["waves_per_simd"] = int(c.grid_blocks) // cus
         if "valu_insts_per_simd_cycle" in pmc:
             # the other reading of the same roofline: how busy the vector pipe is, whatever
             # the instructions compute (a SIMD issues at most one VALU instruction per two cycles)
