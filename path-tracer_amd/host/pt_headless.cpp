@@ -75,7 +75,8 @@ int main(int argc, char *argv[])
         if (!scene_file.empty()) {
             std::ifstream in(scene_file);
             if (!in) { std::cerr << "cannot open " << scene_file << std::endl; return 2; }
-            try { scene.emplace(pt::load_scene(in)); }
+            const size_t cut = scene_file.find_last_of('/');
+            try { scene.emplace(pt::load_scene(in, cut == std::string::npos ? std::string() : scene_file.substr(0, cut))); }
             catch (const pt::SceneFileError &e) { std::cerr << e.what() << std::endl; return 2; }
             scene_name = scene_file;
         } else if (!Scenes::by_name(scene_name.c_str(), scene)) {

@@ -66,7 +66,9 @@ int pt_host_load_scene(const char *path, int width, int height, pt_surface *surf
     try {
         std::ifstream in(path);
         if (!in) throw std::runtime_error(std::string("cannot open ") + path);
-        const Scene scene = pt::load_scene(in);
+        const std::string file(path);
+        const size_t cut = file.find_last_of('/');
+        const Scene scene = pt::load_scene(in, cut == std::string::npos ? std::string() : file.substr(0, cut));
         return emit(scene, width, height, surfaces, materials, capacity, n_surfaces, bg, camera);
     } catch (const std::exception &e) {
         g_host_error = e.what();

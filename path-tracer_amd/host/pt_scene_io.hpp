@@ -10,12 +10,20 @@
 //   material  NAME  diffuse|mirror|glass  r g b  [er eg eb]
 //   sphere  cx cy cz  radius  MATERIAL
 //   triangle  x0 y0 z0  x1 y1 z1  x2 y2 z2  MATERIAL
+//   mesh  FILE.obj  MATERIAL  [scale [tx ty tz]]   the faces of a Wavefront OBJ file as triangles
+//                                            (vertex * scale + t; FILE relative to the scene file)
+//
+// Of an OBJ file the `v` and `f` statements are read: a face's vertices may be
+// written v, v/vt, v//vn or v/vt/vn, counted from 1 or, negative, back from the
+// last vertex read so far; a face of more than three vertices becomes a fan
+// round its first vertex.  Everything else in the file is skipped.
 //
 // Surfaces keep file order (the order breaks distance ties).  Numbers are
 // written with 9 significant digits, which round-trips every fp32 value.
 #pragma once
 
 #include <cstdio>
+#include <fstream>
 #include <istream>
 #include <map>
 #include <ostream>
@@ -34,7 +42,52 @@ class SceneFileError : public std::runtime_error {
     int line;
 };
 
-inline Scene load_scene(std::istream &in)
+// Appends the faces of an OBJ stream to `surfaces`, in file order.  Returns the
+// number of triangles added.  `what` names the stream in error messages.
+inline int load_obj(std::istream &in, std::vector<std::unique_ptr<Surface>> &surfaces, const Material &material,
+                    float scale = 1.0f, vec3 offset = vec3(0, 0, 0), const std::string &what = "OBJ")
+{
+    std::vector<vec3> vertices;
+    std::string line;
+    int line_no = 0, added = 0;
+    auto fail = [&](const std::string &why) {
+        throw std::runtime_error(what + " line " + std::to_string(line_no) + ": " + why);
+    };
+    while (std::getline(in, line)) {
+        line_no++;
+        const size_t hash = line.find('#');
+        if (hash != std::string::npos) line.erase(hash);
+        std::istringstream ss(line);
+        std::string word;
+        if (!(ss >> word)) continue;
+        if (word == "v") {
+            float x, y, z;
+            if (!(ss >> x >> y >> z)) fail("a vertex needs three coordinates");
+            vertices.push_back(vec3(x * scale + offset.x, y * scale + offset.y, z * scale + offset.z));
+        } else if (word == "f") {
+            std::vector<int> corner;
+            std::string ref;
+            while (ss >> ref) {
+                long index = 0;
+                try { index = std::stol(ref.substr(0, ref.find('/'))); }
+                catch (const std::exception &) { fail("bad vertex reference '" + ref + "'"); }
+                const long n = static_cast<long>(vertices.size());
+                const long at = index > 0 ? index - 1 : n + index;
+                if (index == 0 || at < 0 || at >= n) fail("vertex reference '" + ref + "' out of range");
+                corner.push_back(static_cast<int>(at));
+            }
+            if (corner.size() < 3) fail("a face needs three vertices");
+            for (size_t k = 1; k + 1 < corner.size(); k++) {
+                add_surface(surfaces, Triangle(vertices[corner[0]], vertices[corner[k]], vertices[corner[k + 1]], material));
+                added++;
+            }
+        }
+    }
+    return added;
+}
+
+// base_dir: where `mesh` statements look for their files ("" = the working directory).
+inline Scene load_scene(std::istream &in, const std::string &base_dir = "")
 {
     std::vector<std::unique_ptr<Surface>> surfaces;
     std::map<std::string, Material> materials;
@@ -112,6 +165,17 @@ inline Scene load_scene(std::istream &in)
             need(ss, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], name);
             add_surface(surfaces, Triangle(vec3(v[0], v[1], v[2]), vec3(v[3], v[4], v[5]), vec3(v[6], v[7], v[8]),
                                            material_named(name)));
+        } else if (word == "mesh") {
+            std::string file, name;
+            float scale = 1.0f, tx = 0, ty = 0, tz = 0;
+            need(ss, file, name);
+            if (ss >> scale) { if (ss >> tx) need(ss, ty, tz); }
+            const Material &m = material_named(name);
+            const std::string path = (base_dir.empty() || file[0] == '/') ? file : base_dir + "/" + file;
+            std::ifstream obj(path);
+            if (!obj) throw SceneFileError(line_no, "cannot open mesh '" + path + "'");
+            try { load_obj(obj, surfaces, m, scale, vec3(tx, ty, tz), path); }
+            catch (const std::runtime_error &e) { throw SceneFileError(line_no, e.what()); }
         } else {
             throw SceneFileError(line_no, "unknown statement '" + word + "'");
         }

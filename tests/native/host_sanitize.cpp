@@ -119,6 +119,27 @@ int main(int argc, char **argv)
         CHECK(n == 2 && m[0].type == 1 && m[1].emittance[0] == 5.0f && cam.dof_on == 1 && cam.focal == 16.0f);
         CHECK(bg[1] == 0.2f);
     }
+    // OBJ meshes through the `mesh` statement: good and malformed files
+    {
+        const std::string obj = tmp + "/sanitize_mesh.obj", path = tmp + "/sanitize_mesh.txt";
+        { std::ofstream out(path); out << "camera 0 0 -3 0 0 auto\nmaterial a diffuse 1 1 1\nmesh sanitize_mesh.obj a 0.5 1 2 3\n"; }
+        const char *meshes[] = {
+            "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1 2 3 4\nf -1/2/3 -2//1 -3\n",   // 3 triangles
+            "v 0 0 0\nf 1 2 3\n", "v 0 0 0\nv 1 1 1\nv 2 2 2\nf 1 2\n", "v 1 2\n", "v 0 0 0\nv 1 1 1\nv 2 2 2\nf 0 1 2\n",
+            "v 0 0 0\nv 1 1 1\nv 2 2 2\nf 1 2 99999999999999999999\n", "v 0 0 0\nv 1 1 1\nv 2 2 2\nf -4 1 2\n", "f\n",
+        };
+        for (size_t k = 0; k < sizeof meshes / sizeof *meshes; k++) {
+            { std::ofstream out(obj); out << meshes[k]; }
+            int32_t n = 0;
+            float bg[3];
+            pt_camera cam;
+            pt_surface s[4];
+            pt_material m[4];
+            const int rc = pt_host_load_scene(path.c_str(), 8, 8, s, m, 4, &n, bg, &cam);
+            if (k == 0) CHECK(rc == 0 && n == 3 && s[0].a[0] == 1.0f && s[0].b[0] == 1.5f && s[2].kind == PT_TRIANGLE);
+            else CHECK(rc == -3 && std::strlen(pt_host_last_error()) > 0);
+        }
+    }
     for (int off = 0; off < 2; off++) {
         float rot[9];
         pt_host_camera_matrix(0.3f, -1.2f, off, rot);

@@ -91,3 +91,72 @@ def test_scene_file_errors(pt, tmp_path, text, fragment):
     assert fragment in str(e.value) and "line" in str(e.value)
     with pytest.raises(ValueError):
         pt.load_scene_file(tmp_path / "missing.txt", 32, 32)
+
+
+CUBE_OBJ = """# a unit cube: quads, a pentagon-free mix of reference styles
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+v 0 0 1
+v 1 0 1
+v 1 1 1
+v 0 1 1
+vt 0 0
+vn 0 0 1
+f 1 2 3 4
+f 5/1 6/1 7/1 8/1
+f 1//1 2//1 6//1 5//1
+f 2/1/1 3/1/1 7/1/1 6/1/1
+f -6 -5 -1 -2          # 3 4 8 7 counted back from the last vertex
+o ignored
+usemtl ignored
+f 4 1 5
+f 4 5 8
+"""
+
+
+def test_scene_file_with_obj_mesh(pt, tmp_path):
+    """The `mesh` statement: faces of an OBJ file as triangles, quads as fans, scaled and moved,
+    in file order between the other surfaces."""
+    (tmp_path / "cube.obj").write_text(CUBE_OBJ)
+    path = tmp_path / "scene.txt"
+    path.write_text("""camera 0 0 -3  0 0  auto
+material grey diffuse 0.5 0.5 0.5
+material lamp diffuse 1 1 1  3 3 3
+sphere 0 -3 0 1 lamp
+mesh cube.obj grey 2 -1 -1 4
+sphere 0 0 0 0.25 grey
+""")
+    sc = pt.load_scene_file(path, 64, 48)
+    kinds = list(sc.surfaces["kind"])
+    assert kinds == [pt.SPHERE] + [pt.TRIANGLE] * 12 + [pt.SPHERE]
+    tri = sc.surfaces[1:13]
+    assert (tri["material"] == tri["material"][0]).all() or len(set(tri["material"])) == 12
+    # first quad 1 2 3 4 -> (1,2,3) and (1,3,4), vertex * 2 + (-1,-1,4)
+    assert np.array_equal(tri["a"][0], [-1, -1, 4]) and np.array_equal(tri["b"][0], [1, -1, 4])
+    assert np.array_equal(tri["c"][0], [1, 1, 4])
+    assert np.array_equal(tri["a"][1], [-1, -1, 4]) and np.array_equal(tri["b"][1], [1, 1, 4])
+    assert np.array_equal(tri["c"][1], [-1, 1, 4])
+    # the face written with negative references is 3 4 8 7
+    assert np.array_equal(tri["a"][8], [1, 1, 4]) and np.array_equal(tri["b"][8], [-1, 1, 4])
+    assert np.array_equal(tri["c"][8], [-1, 1, 6])
+    corners = np.concatenate([tri["a"], tri["b"], tri["c"]])
+    assert corners.min(0).tolist() == [-1, -1, 4] and corners.max(0).tolist() == [1, 1, 6]
+
+
+@pytest.mark.parametrize("obj,fragment", [
+    ("v 0 0 0\nv 1 0 0\nf 1 2 3\n", "out of range"),
+    ("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2\n", "three vertices"),
+    ("v 0 0\n", "three coordinates"),
+    ("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 x 3\n", "bad vertex reference"),
+    (None, "cannot open mesh"),
+])
+def test_obj_mesh_errors(pt, tmp_path, obj, fragment):
+    if obj is not None:
+        (tmp_path / "m.obj").write_text(obj)
+    path = tmp_path / "scene.txt"
+    path.write_text("camera 0 0 0 0 0 auto\nmaterial g diffuse 1 1 1\nmesh m.obj g\n")
+    with pytest.raises(ValueError) as e:
+        pt.load_scene_file(path, 32, 32)
+    assert fragment in str(e.value) and "scene file line 3" in str(e.value)
