@@ -816,3 +816,47 @@ def test_scan_by_runs_of_one_kind_on_interleaved_kinds(ctx, pt, orc):
     oacc, ocnt = orc.render(as_oracle_scene(orc, sc), 6, first_sample=2, seed=5, threads=8)
     frac = np.isclose(mega, oacc, rtol=2e-3, atol=2e-3).all(axis=2).mean()
     assert frac >= 0.95 and abs(cm.segments - ocnt.segments) <= 0.01 * ocnt.segments
+
+
+def test_obj_mesh_scene_through_the_hierarchy(ctx, pt, orc, tmp_path):
+    """A user scene as data: a torus of 2,048 triangles from an OBJ file (quads, so fans) plus a
+    lamp and a floor from the scene file.  Enough triangles for the hierarchy under PT_ACCEL_AUTO:
+    camera-ray hits equal the oracle's bit for bit, and the render equals the scan's."""
+    nu, nv, R, r = 64, 16, 1.0, 0.35
+    lines = []
+    for i in range(nu):
+        for j in range(nv):
+            a, b = 2 * np.pi * i / nu, 2 * np.pi * j / nv
+            lines.append("v %.9g %.9g %.9g" % ((R + r * np.cos(b)) * np.cos(a), r * np.sin(b), (R + r * np.cos(b)) * np.sin(a)))
+    for i in range(nu):
+        for j in range(nv):
+            q = [i * nv + j, ((i + 1) % nu) * nv + j, ((i + 1) % nu) * nv + (j + 1) % nv, i * nv + (j + 1) % nv]
+            lines.append("f " + " ".join(str(k + 1) for k in q))
+    (tmp_path / "torus.obj").write_text("\n".join(lines) + "\n")
+    path = tmp_path / "scene.txt"
+    path.write_text("""camera 0 -1.2 -3.2  -0.35 0  auto
+background 0.05 0.05 0.08
+material clay diffuse 0.8 0.5 0.3
+material floor diffuse 0.7 0.7 0.7
+material lamp diffuse 1 1 1  6 6 6
+sphere 0 -4 0 1.5 lamp
+mesh torus.obj clay
+triangle -6 0.6 -6  0 0.6 12  6 0.6 -6 floor
+""")
+    sc = pt.load_scene_file(path, 160, 120)
+    assert sc.n_triangles == 2 * nu * nv + 1 and sc.n_spheres == 1
+    load(ctx, sc)
+    idx, dist = ctx.primary_hits()
+    oidx, odist = orc.primary_hits(as_oracle_scene(orc, sc))
+    assert np.array_equal(idx, oidx) and np.array_equal(dist, odist)
+    on_torus = ((idx >= 1) & (idx <= 2 * nu * nv)).mean()
+    assert 0.1 < on_torus < 0.9
+    acc, cnt = render(ctx, pt, sc, 8, seed=6)
+    assert cnt.accel == pt.ACCEL_BVH
+    try:
+        ctx.set_accel(pt.ACCEL_NONE)
+        scan, scnt = render(ctx, pt, sc, 8, seed=6)
+    finally:
+        ctx.set_accel(pt.ACCEL_AUTO)
+    assert scnt.accel == pt.ACCEL_NONE and scnt.segments == cnt.segments and np.array_equal(scan, acc)
+    assert acc.sum() > 0
