@@ -399,6 +399,15 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
     P.chunk_len = chunk_len;
     P.n_pixels = n_pixels;
     P.n_items = (uint32_t)n_items64;
+    // Items a wave takes per atomic on the queue head: about 256 samples' worth.  Every wave of
+    // the launch adds to that one word, which takes some 140 adds per microsecond; with one-sample
+    // items (launches of a few samples per pixel) batches of 64 ask for more than that
+    // (800x800, 16 spp: 2046 us; with 256: 912 us), while large batches of large items
+    // leave the last waves with too much (1024 spp: 64 items 41.7 ms, 256 items 43.8 ms).
+    // (A hierarchy scene spends far longer per item: no pressure on the queue head, and the
+    // smaller batch ends sooner, 12.6 against 13.3 ms on the million-triangle field at 16 spp.)
+    P.pool_batch = std::min(std::max((256u + chunk_len - 1) / chunk_len, POOL_BATCH_MIN), POOL_BATCH_MAX);
+    if constexpr (KIND == SCENE_BVH) P.pool_batch = POOL_BATCH_MIN;
     P.slabs = ctx->d_slabs;
     P.queue_head = ctx->d_queue;
     P.stats = reinterpret_cast<unsigned long long *>(ctx->d_queue + 2);

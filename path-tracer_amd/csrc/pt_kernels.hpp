@@ -7,7 +7,8 @@
 namespace ptd {
 
 constexpr int BLOCK = 256;           // 4 waves of 64
-constexpr uint32_t POOL_BATCH = 64;  // work items a wave takes from the global queue at a time
+constexpr uint32_t POOL_BATCH_MIN = 64;    // work items a wave takes from the global queue at a time:
+constexpr uint32_t POOL_BATCH_MAX = 256;   // at least a wave's width; the host picks (RenderParams::pool_batch)
 constexpr uint32_t NO_ITEM = 0xFFFFFFFFu;
 constexpr int MAX_DEPTH = 1024;      // PT_MAX_DEPTH
 // The hierarchy megakernel runs its shading block when at least NUM/DEN of a wave's live lanes wait
@@ -67,6 +68,7 @@ struct RenderParams {
     uint32_t n_pixels;
     uint32_t n_items;         // n_pixels * ceil(spp / chunk_len); item = chunk * n_pixels + pixel
     float *slabs;             // n_items * 3 partial sums, slab of chunk k at k * n_pixels * 3
+    uint32_t pool_batch;      // work items a wave takes from the queue per atomic (POOL_BATCH_MIN..MAX)
     uint32_t *queue_head;     // zeroed before the launch
     unsigned long long *stats;  // [0] += segments, [1] += segments re-evaluated directly
 };
@@ -347,10 +349,10 @@ PT_DEV bool path_segment(PathState &ps, const SceneView &sc, const float *shade,
 struct WorkPool { uint32_t next, end; bool drained; };
 
 // Hands one work item to every lane with want = true, refilling the pool with
-// POOL_BATCH items from the global head when it runs short (one atomic per
+// `batch` items (>= 64) from the global head when it runs short (one atomic per
 // refill).  Must be called by every live lane of the wave together.  Returns
 // NO_ITEM to a lane once the queue is empty.
-PT_DEV uint32_t pool_take(WorkPool &pool, bool want, uint32_t *queue_head, uint32_t n_items)
+PT_DEV uint32_t pool_take(WorkPool &pool, bool want, uint32_t *queue_head, uint32_t n_items, uint32_t batch)
 {
     const uint32_t lane = __lane_id();
     const unsigned long long mask = __ballot(want);
@@ -367,10 +369,10 @@ PT_DEV uint32_t pool_take(WorkPool &pool, bool want, uint32_t *queue_head, uint3
     uint32_t base = n_items;
     if (!pool.drained) {
         uint32_t b = 0;
-        if (lane == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) b = atomicAdd(queue_head, POOL_BATCH);
+        if (lane == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) b = atomicAdd(queue_head, batch);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
     }
-    uint32_t end = base + POOL_BATCH;
+    uint32_t end = base + batch;
     if (base >= n_items) { base = end = n_items; pool.drained = true; }
     else if (end > n_items) end = n_items;
     if (want && rank >= avail && base + (rank - avail) < end) got = base + (rank - avail);
@@ -416,7 +418,7 @@ PT_DEV void item_close(ItemState &it, float *slabs)
 // time, traces its paths one segment per loop iteration, and starts the next
 // path - or fetches the next item - in the iteration after a path ends, so
 // lanes of a wave stay busy whatever the lengths of their paths.  Items come
-// from a global counter, POOL_BATCH at a time per wave, and are handed to
+// from a global counter, P.pool_batch at a time per wave, and are handed to
 // lanes from a wave-uniform pool.  A lane leaves the loop when the queue is
 // empty: every wave reaches that state, so the grid always drains.
 //
@@ -449,7 +451,7 @@ k_render_mega(RenderParams P)
         const bool want = need_path && it.s == it.s_end;
         if (__any(want)) {                      // wave-uniform: every live lane enters
             if (want && it.have) item_close(it, P.slabs);
-            const uint32_t got = pool_take(pool, want, P.queue_head, P.n_items);
+            const uint32_t got = pool_take(pool, want, P.queue_head, P.n_items, P.pool_batch);
             if (want) {
                 if (got == NO_ITEM) break;      // queue empty: this lane retires
                 item_open(it, got, P.cam.width, P.n_pixels, P.first_sample, P.spp, P.chunk_len, P.seed_mix);
@@ -528,7 +530,7 @@ k_render_mega_bvh(RenderParams P)
             const bool want = need_path && it.s == it.s_end;
             if (__any(want)) {
                 if (want && it.have) item_close(it, P.slabs);
-                const uint32_t got = pool_take(pool, want, P.queue_head, P.n_items);
+                const uint32_t got = pool_take(pool, want, P.queue_head, P.n_items, P.pool_batch);
                 if (want) {
                     if (got == NO_ITEM) alive = false;       // queue empty: this lane retires
                     else item_open(it, got, P.cam.width, P.n_pixels, P.first_sample, P.spp, P.chunk_len, P.seed_mix);

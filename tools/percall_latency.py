@@ -19,3 +19,23 @@ for w, h, spp in ((356, 200, 1), (800, 800, 1), (800, 800, 4), (800, 800, 16), (
     ks.sort()
     print("%dx%d %d spp: kernel median %.1f us, blocks %d" % (w, h, spp, ks[len(ks) // 2], ctx.counters().grid_blocks), flush=True)
     ctx.close()
+
+# Wall time per call when calls are queued back to back (what an interactive loop pays per frame):
+# the render call alone, then with the tone map and the image read back every frame.
+for w, h in ((356, 200), (800, 800)):
+    scene = pt_amd.builtin_scene("cornell_2", w, h)
+    ctx = pt_amd.Context(0); ctx.load(scene)
+    for i in range(10): ctx.render(1, i, 1, 0)
+    ctx.read_accum()
+    n = 200
+    t0 = time.perf_counter()
+    for i in range(n): ctx.render(1, 10 + i, 1, 0)
+    ctx.read_accum()
+    t1 = time.perf_counter()
+    for i in range(n):
+        ctx.render(1, 10 + n + i, 1, 0)
+        ctx.tonemap_rgb8()
+    t2 = time.perf_counter()
+    print("%dx%d 1 spp per call: %.0f us per pt_render queued back to back, %.0f us per frame with tone map and read-back" % (
+        w, h, (t1 - t0) / n * 1e6, (t2 - t1) / n * 1e6), flush=True)
+    ctx.close()
