@@ -352,7 +352,13 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
             kernel = &k_render_mega<FAST, KIND, true>;
     }
     const double samples = (double)n_pixels * spp;
-    const int blocks_wanted = std::max(1, (int)std::lround(std::sqrt(samples / 3e5)));
+    // Workgroups per CU (= waves per SIMD) for this launch: one more for every doubling of the
+    // launch, from 2e5 samples on.  A small launch ends when its longest path does, and a wave's
+    // iteration takes the longer the more waves share its SIMD, so fewer, busier waves finish
+    // such a launch sooner.  Measured (kernel us; 800x800 cornell_2 at 1/2/4/8/16 spp): all
+    // that fit 317/355/457/623/938, this rule 219/294/401/587/925; the million-triangle
+    // field at 1 spp 2949 -> 2733, 80 spheres 1113 -> 1089; 356x200 at 1 spp 259 -> 124.
+    const int blocks_wanted = std::max(1, (int)std::lround(0.9 + std::log2(std::max(samples, 1.0) / 2e5)));
     if constexpr (KIND == SCENE_BVH) {
         kernel = &k_render_mega_bvh<FAST>;
         if (blocks_wanted >= 7) kernel = &k_render_mega_bvh<FAST, 7>;
@@ -360,11 +366,6 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
     int blocks_per_cu = 0;
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, BLOCK, lds_bytes));
     if (blocks_per_cu < 1) return fail(ctx, PT_E_HIP, "render kernel does not fit on a compute unit");
-    // A small launch ends when its longest path does, and one loop iteration takes
-    // about as long with two waves on a SIMD as with eight: fewer, busier waves
-    // finish such a launch sooner.  Measured against launching all that fit:
-    // 356x200 at 1 spp 244 -> 124 us (one workgroup per CU), 800x800 at 4 spp
-    // 698 -> 609 us (three); from about 64 spp at 800x800 all that fit is fastest.
     blocks_per_cu = std::min(blocks_per_cu, blocks_wanted);
     const uint32_t grid = (uint32_t)blocks_per_cu * (uint32_t)ctx->num_cus;
     const uint64_t lanes = (uint64_t)grid * BLOCK;
@@ -406,7 +407,11 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
     // leave the last waves with too much (1024 spp: 64 items 41.7 ms, 256 items 43.8 ms).
     // (A hierarchy scene spends far longer per item: no pressure on the queue head, and the
     // smaller batch ends sooner, 12.6 against 13.3 ms on the million-triangle field at 16 spp.)
-    P.pool_batch = std::min(std::max((256u + chunk_len - 1) / chunk_len, POOL_BATCH_MIN), POOL_BATCH_MAX);
+    // And never so many that a launch of few items feeds only some of its waves (356x200 at
+    // 1 spp is 71k items for 1024 waves: 143 us with batches of 256, 121 us with 69).
+    const uint64_t fair = n_items64 / (lanes / 64);
+    P.pool_batch = (uint32_t)std::min<uint64_t>((256u + chunk_len - 1) / chunk_len, fair);
+    P.pool_batch = std::min(std::max(P.pool_batch, POOL_BATCH_MIN), POOL_BATCH_MAX);
     if constexpr (KIND == SCENE_BVH) P.pool_batch = POOL_BATCH_MIN;
     P.slabs = ctx->d_slabs;
     P.queue_head = ctx->d_queue;
