@@ -163,6 +163,15 @@ int pt_render_into(pt_ctx *ctx, float *accum_device, uint32_t spp, uint32_t firs
  * Either pointer may be NULL. */
 int pt_read_accum(pt_ctx *ctx, float *rgb_sum_host, uint64_t *total_samples);
 
+/* The same image without a copy of the caller's: the sums are read back into
+ * page-locked host memory that the context owns (the fast path across PCIe) and
+ * *rgb_sum_host points at it, height*width*3 floats row-major.  The memory stays
+ * valid, and keeps these values, until the next pt_map_accum on this context,
+ * a pt_set_camera that changes the image size, or pt_destroy.  For a caller that
+ * adds every pass to a host-side BUFFER, as trace_rays does (src/main.cpp:139).
+ * total_samples may be NULL. */
+int pt_map_accum(pt_ctx *ctx, const float **rgb_sum_host, uint64_t *total_samples);
+
 /* Replaces the accumulation buffer and the sample counter with caller data
  * (height*width*3 floats, row-major, in host or device memory): resumes an
  * image read back earlier with pt_read_accum, hands a host-side BUFFER to

@@ -83,6 +83,8 @@ struct pt_ctx {
     float *d_bvh_leaves = nullptr;
 
     float *d_accum = nullptr;        // height*width*3 running sums
+    float *h_mapped = nullptr;       // pt_map_accum's page-locked copy of them (allocated on first use)
+    size_t mapped_floats = 0;
     size_t accum_floats = 0;
     uint64_t total_samples = 0;
 
@@ -647,6 +649,7 @@ void pt_destroy(pt_ctx *ctx)
     if (ctx->d_loose) (void)hipFree(ctx->d_loose);
     if (ctx->d_bvh_nodes) (void)hipFree(ctx->d_bvh_nodes);      // the leaves live in the same allocation
     if (ctx->d_accum) (void)hipFree(ctx->d_accum);
+    if (ctx->h_mapped) (void)hipHostFree(ctx->h_mapped);
     if (ctx->d_slabs) (void)hipFree(ctx->d_slabs);
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     if (ctx->d_wf) (void)hipFree(ctx->d_wf);
@@ -839,6 +842,28 @@ int pt_read_accum(pt_ctx *ctx, float *rgb_sum_host, uint64_t *total_samples)
                                     hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
+    if (total_samples) *total_samples = ctx->total_samples;
+    return PT_OK;
+}
+
+int pt_map_accum(pt_ctx *ctx, const float **rgb_sum_host, uint64_t *total_samples)
+{
+    if (!ctx) return fail(nullptr, PT_E_INVALID, "null context");
+    if (!rgb_sum_host) return fail(ctx, PT_E_INVALID, "rgb_sum_host is null");
+    if (!ctx->have_camera) return fail(ctx, PT_E_INVALID, "pt_set_camera has not been called");
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if (ctx->mapped_floats != ctx->accum_floats) {
+        if (ctx->h_mapped) (void)hipHostFree(ctx->h_mapped);
+        ctx->h_mapped = nullptr;
+        ctx->mapped_floats = 0;
+        HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_mapped), ctx->accum_floats * sizeof(float), hipHostMallocDefault));
+        ctx->mapped_floats = ctx->accum_floats;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mapped, ctx->d_accum, ctx->accum_floats * sizeof(float),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *rgb_sum_host = ctx->h_mapped;
     if (total_samples) *total_samples = ctx->total_samples;
     return PT_OK;
 }

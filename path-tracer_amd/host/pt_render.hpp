@@ -175,6 +175,15 @@ class Renderer {
         return sums;
     }
 
+    // The same without a copy of the caller's: a view of page-locked memory the context
+    // owns, valid until the next call of this function.
+    const float *map_sums() const
+    {
+        const float *sums = nullptr;
+        check(pt_map_accum(ctx_, &sums, nullptr));
+        return sums;
+    }
+
     // Replaces the device image with host sums (row-major) and their sample count.
     void write_sums(const std::vector<float> &sums, uint64_t total_samples)
     {
@@ -276,12 +285,15 @@ inline void trace_rays(Scene &scene, BUFFER &buffer, uint32_t spp = 1)
     r.sync(scene, width, height);
     r.clear();                                   // the host buffer holds the running sums
     r.render(spp);
-    const std::vector<float> sums = r.read_sums();
-    for (int u = 0; u < width; u++) {
-        std::vector<vec3> &column = buffer[u];
+    const float *sums = r.map_sums();
+    // the device image is row-major, BUFFER is a vector of columns: a few columns at a
+    // time, so that a row's pixels are read while their cache lines are still there
+    constexpr int COLUMNS = 16;
+    for (int u0 = 0; u0 < width; u0 += COLUMNS) {
+        const int u1 = u0 + COLUMNS < width ? u0 + COLUMNS : width;
         for (int v = 0; v < height; v++) {
-            const float *p = &sums[3 * (static_cast<size_t>(v) * width + u)];
-            column[v] += vec3(p[0], p[1], p[2]);
+            const float *p = sums + 3 * (static_cast<size_t>(v) * width + u0);
+            for (int u = u0; u < u1; u++, p += 3) buffer[u][v] += vec3(p[0], p[1], p[2]);
         }
     }
     TOTAL_SAMPLES += spp;

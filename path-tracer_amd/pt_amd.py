@@ -34,7 +34,7 @@ SCENE_NAMES = ("dof_demo", "test", "orange_plane", "red_corner", "sunrise",
 ABI_SYMBOLS = (
     "pt_global_error", "pt_create", "pt_destroy", "pt_last_error", "pt_set_stream",
     "pt_set_scene", "pt_set_accel", "pt_set_camera", "pt_clear", "pt_render", "pt_render_into",
-    "pt_read_accum", "pt_write_accum", "pt_tonemap_rgb8", "pt_primary_hits", "pt_intersect_rays",
+    "pt_read_accum", "pt_map_accum", "pt_write_accum", "pt_tonemap_rgb8", "pt_primary_hits", "pt_intersect_rays",
     "pt_camera_rays", "pt_eval_bsdf", "pt_eval_brdf", "pt_rng_uniform", "pt_get_counters",
 )
 
@@ -245,6 +245,14 @@ class Context:
         total = C.c_uint64(0)
         self._check(self._lib.pt_read_accum(self._h, _p(out), C.byref(total)))
         return out, total.value
+
+    def map_accum(self):
+        """The running sums as a (height, width, 3) view of page-locked memory the context
+        owns (valid until the next map_accum), and the sample count."""
+        ptr = C.POINTER(C.c_float)()
+        total = C.c_uint64(0)
+        self._check(self._lib.pt_map_accum(self._h, C.byref(ptr), C.byref(total)))
+        return np.ctypeslib.as_array(ptr, shape=(self.height, self.width, 3)), int(total.value)
 
     def write_accum(self, sums, total_samples):
         sums = np.ascontiguousarray(sums, dtype=np.float32)

@@ -860,3 +860,20 @@ triangle -6 0.6 -6  0 0.6 12  6 0.6 -6 floor
         ctx.set_accel(pt.ACCEL_AUTO)
     assert scnt.accel == pt.ACCEL_NONE and scnt.segments == cnt.segments and np.array_equal(scan, acc)
     assert acc.sum() > 0
+
+
+def test_mapped_read_back_equals_the_copy(ctx, pt):
+    """pt_map_accum: the sums in page-locked memory of the context's, for two image sizes."""
+    for w, h in ((64, 40), (96, 72)):
+        load(ctx, pt.builtin_scene("cornell_2", w, h))
+        ctx.clear()
+        ctx.render(3, 0, 2, 0)
+        copy, total = ctx.read_accum()
+        view, mtotal = ctx.map_accum()
+        assert view.shape == (h, w, 3) and mtotal == total == 3
+        assert np.array_equal(view, copy) and copy.sum() > 0
+        ctx.render(2, 3, 2, 0)
+        kept = view.copy()
+        again, mtotal = ctx.map_accum()          # the same memory, refreshed
+        assert mtotal == 5 and not np.array_equal(again, kept)
+        assert np.array_equal(again, ctx.read_accum()[0])
