@@ -347,8 +347,9 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
     const size_t lds_bytes = lds_bytes_for(ctx, KIND);
 
     // scenes with a hierarchy have a megakernel of their own
-    void (*kernel)(RenderParams) = &k_render_mega<FAST, KIND>;
+    void (*kernel)(RenderParams) = nullptr;
     if constexpr (KIND != SCENE_BVH) {
+        kernel = &k_render_mega<FAST, KIND>;
         // many spheres or many (then small) triangles: most waves miss most of them (see scan_surface)
         if (ctx->n_sph >= WAVE_SKIP_MIN_SPHERES || ctx->n_tri >= WAVE_SKIP_MIN_TRIANGLES)
             kernel = &k_render_mega<FAST, KIND, true>;
