@@ -364,7 +364,7 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
     const int blocks_wanted = std::max(1, (int)std::lround(0.9 + std::log2(std::max(samples, 1.0) / 2e5)));
     if constexpr (KIND == SCENE_BVH) {
         kernel = &k_render_mega_bvh<FAST>;
-        if (blocks_wanted >= 7) kernel = &k_render_mega_bvh<FAST, 7>;
+        if (blocks_wanted >= 8) kernel = &k_render_mega_bvh<FAST, 7>;       // from 2e7 samples on
     }
     int blocks_per_cu = 0;
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, BLOCK, lds_bytes));
