@@ -243,9 +243,11 @@ int build_hierarchy(pt_ctx *ctx, const pt_surface *surfaces, int n_surfaces)
     }
     const float ray_reach = std::min(4.0f * (extent[0] + extent[1] + extent[2]), 1e30f);
     float3 gmin = make_float3(cmin[0], cmin[1], cmin[2]), ginv;
-    ginv.x = cmax[0] > cmin[0] ? 1.0f / (cmax[0] - cmin[0]) : 0.0f;
-    ginv.y = cmax[1] > cmin[1] ? 1.0f / (cmax[1] - cmin[1]) : 0.0f;
-    ginv.z = cmax[2] > cmin[2] ? 1.0f / (cmax[2] - cmin[2]) : 0.0f;
+    // one scale for the three axes (the grid is a cube round the centroids): an axis along
+    // which the scene is thin then spends few code bits, and the hierarchy's early splits
+    // fall along the axes on which the triangles actually spread
+    const float widest = std::max({cmax[0] - cmin[0], cmax[1] - cmin[1], cmax[2] - cmin[2]});
+    ginv.x = ginv.y = ginv.z = widest > 0.0f ? 1.0f / widest : 0.0f;
 
     int rc;
     Scratch<int> d_inside, d_parent_node, d_parent_leaf;
