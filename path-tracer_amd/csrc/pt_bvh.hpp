@@ -20,7 +20,7 @@ constexpr int BVH_MAX_LEAVES = 1 << 25;          // nodes + leaves, 64 bytes eac
 constexpr float BVH_ORIGIN_ROUNDING = 8e-6f;     // of |o|: some 60 ulps
 // A leaf is one triangle: its geometry record (GEOM_STRIDE floats) with the
 // surface's index in scene order in element 3 (where a geometry record keeps the kind).
-constexpr int BVH_STACK = 64;        // deepest possible tree: 30 Morton bits + 32 index bits
+constexpr int BVH_STACK = 64;        // deepest possible tree: one level per key bit
 // Where the per-lane traversal stacks live.  In LDS they cost 64 KiB per
 // workgroup, which leaves two workgroups per CU; in private memory they cost
 // write-through traffic but no occupancy.  Measured on the million-triangle
@@ -42,17 +42,28 @@ struct BvhView {
 
 // ---------------------------------------------------------------- build
 
-PT_DEV uint32_t spread10(uint32_t v)     // 10 bits -> every third bit
+// Sort key of a hierarchy triangle: Morton code of its centroid, BVH_CODE_BITS per axis,
+// above its number among the hierarchy's triangles (so keys are unique and the number
+// can be read back from a sorted key).
+constexpr int BVH_INDEX_BITS = 25;                       // BVH_MAX_LEAVES = 1 << 25
+constexpr int BVH_CODE_BITS = 13;                        // 3 * 13 + 25 = 64
+static_assert((1 << BVH_INDEX_BITS) == BVH_MAX_LEAVES && 3 * BVH_CODE_BITS + BVH_INDEX_BITS <= 64, "key layout");
+
+PT_DEV unsigned long long spread_bits(unsigned long long v)     // up to 21 bits -> every third bit
 {
-    v = (v | (v << 16)) & 0x030000FFu;
-    v = (v | (v << 8)) & 0x0300F00Fu;
-    v = (v | (v << 4)) & 0x030C30C3u;
-    v = (v | (v << 2)) & 0x09249249u;
+    v &= 0x1fffffull;
+    v = (v | (v << 32)) & 0x1f00000000ffffull;
+    v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+    v = (v | (v << 8)) & 0x100f00f00f00f00full;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
     return v;
 }
 
+PT_DEV int bvh_key_index(unsigned long long key) { return (int)(key & ((1ull << BVH_INDEX_BITS) - 1ull)); }
+
 // Per hierarchy triangle j (scene index tri_idx[j]): padded box, 64-bit sort key
-// = 30-bit Morton code of the centroid, then j (keys are unique).
+// = Morton code of the centroid, then j (keys are unique).
 // The pad covers the reference's tolerance outside the triangle (u, v >= -1e-5
 // of an edge length), the rounding of hit points, and the rounding of o - v0 in
 // the reference's test for ray origins up to ray_reach from the coordinate
@@ -76,11 +87,12 @@ k_bvh_prepare(const float *geom, const int *tri_idx, int n, float3 cmin, float3 
     const float cx = ((lo.x + hi.x) * 0.5f - cmin.x) * cinv.x;
     const float cy = ((lo.y + hi.y) * 0.5f - cmin.y) * cinv.y;
     const float cz = ((lo.z + hi.z) * 0.5f - cmin.z) * cinv.z;
-    const uint32_t qx = (uint32_t)fminf(fmaxf(cx * 1024.0f, 0.0f), 1023.0f);
-    const uint32_t qy = (uint32_t)fminf(fmaxf(cy * 1024.0f, 0.0f), 1023.0f);
-    const uint32_t qz = (uint32_t)fminf(fmaxf(cz * 1024.0f, 0.0f), 1023.0f);
-    const uint32_t code = (spread10(qx) << 2) | (spread10(qy) << 1) | spread10(qz);
-    keys[j] = ((unsigned long long)code << 32) | (uint32_t)j;
+    constexpr float CELLS = (float)(1 << BVH_CODE_BITS);
+    const uint32_t qx = (uint32_t)fminf(fmaxf(cx * CELLS, 0.0f), CELLS - 1.0f);
+    const uint32_t qy = (uint32_t)fminf(fmaxf(cy * CELLS, 0.0f), CELLS - 1.0f);
+    const uint32_t qz = (uint32_t)fminf(fmaxf(cz * CELLS, 0.0f), CELLS - 1.0f);
+    const unsigned long long code = (spread_bits(qx) << 2) | (spread_bits(qy) << 1) | spread_bits(qz);
+    keys[j] = (code << BVH_INDEX_BITS) | (unsigned long long)j;
 }
 
 // Length of the common prefix of sorted keys i and j; -1 outside the array.
@@ -135,7 +147,7 @@ k_bvh_refit(const unsigned long long *keys, int n, const int2 *children, const i
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
-    const int j = (int)(uint32_t)keys[k];
+    const int j = bvh_key_index(keys[k]);
     float4 lo = box_min[j], hi = box_max[j];
     int child = ~k;
     int p = parent_of_leaf[k];
@@ -172,7 +184,7 @@ k_bvh_leaves(const unsigned long long *keys, int n, const float *geom, const int
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
-    const int i = tri_idx[(int)(uint32_t)keys[k]];
+    const int i = tri_idx[bvh_key_index(keys[k])];
     const float4 *src = reinterpret_cast<const float4 *>(geom + (size_t)i * GEOM_STRIDE);
     float4 *dst = reinterpret_cast<float4 *>(leaves + (size_t)k * GEOM_STRIDE);
     float4 a = src[0];
