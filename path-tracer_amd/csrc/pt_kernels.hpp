@@ -12,8 +12,8 @@ constexpr uint32_t POOL_BATCH_MAX = 256;   // at least a wave's width; the host 
 constexpr uint32_t NO_ITEM = 0xFFFFFFFFu;
 constexpr int MAX_DEPTH = 1024;      // PT_MAX_DEPTH
 // The hierarchy megakernel runs its shading block when at least NUM/DEN of a wave's live lanes wait
-// for it. Measured on the million-triangle heightfield (800x800, 16 spp): 1/8 14.4 ms, 1/4 13.1 ms,
-// 1/2 13.3 ms, 3/4 15.9 ms.
+// for it. Measured on the million-triangle heightfield (800x800, 64 spp): 1/4 21.6 ms, 3/8 18.9 ms,
+// 1/2 18.0 ms, 5/8 18.5 ms, 3/4 20.0 ms.
 constexpr int BVH_REFILL_NUM = 1, BVH_REFILL_DEN = 2;
 constexpr int MAX_LDS_SURFACES = 64 * 1024 / (12 * 4);   // shading records kept in LDS (64 KiB)
 
