@@ -44,8 +44,8 @@ extern "C" {
 #define PT_NUM_FAST        0x10  /* FMA + hardware rcp/rsq/sin/cos */
 
 /* pt_set_accel modes */
-#define PT_ACCEL_AUTO 0   /* hierarchy when the scene has 256 triangles or more (and no more than it
-                             can hold: 2^25; beyond that, the scan) */
+#define PT_ACCEL_AUTO 0   /* hierarchy when the scene has 16 small triangles or more (and no more than
+                             it can hold: 2^25; beyond that, the scan) */
 #define PT_ACCEL_NONE 1   /* always the reference's linear scan over every surface */
 #define PT_ACCEL_BVH  2   /* hierarchy whenever the scene has two small triangles or more;
                              PT_E_LIMIT beyond 2^25 of them */

@@ -172,7 +172,11 @@ int check_ready(pt_ctx *ctx, bool need_camera)
 // Builds the hierarchy over the scene's small triangles on the GPU, or clears
 // it when the scene has too few of them (or PT_ACCEL_NONE is set).  geom is
 // the host copy of the geometry records already uploaded to ctx->d_geom.
-constexpr int BVH_AUTO_MIN_TRIANGLES = 256;
+// PT_ACCEL_AUTO: from this many small triangles on.  Measured at 800 x 800 (scan / hierarchy, ms
+// of kernel at 64, 8 and 1 spp): 8 small triangles + 7 other surfaces 3.9 / 3.2 (64 spp),
+// 0.65 / 0.61, 0.21 / 0.24; 18 + 7: 4.67 / 3.21, 0.84 / 0.63, 0.29 / 0.25; 242 + 7: 26.2 / 3.7,
+// 4.25 / 0.87, 1.42 / 0.34.
+constexpr int BVH_AUTO_MIN_TRIANGLES = 16;
 // Measured, 800 x 800: 80 spheres 46.2 -> 32.2 ms and 249 small triangles 45.0 -> 30.3 ms with the
 // early-outs; 15 triangles 16.4 -> 16.8 ms and the three large spheres of cornell_2 -10 % (hence off).
 constexpr int WAVE_SKIP_MIN_SPHERES = 16, WAVE_SKIP_MIN_TRIANGLES = 32;
@@ -214,7 +218,7 @@ int build_hierarchy(pt_ctx *ctx, const pt_surface *surfaces, int n_surfaces)
         (in ? inside : loose).push_back(i);
     }
     const int n = (int)inside.size();
-    if (n < 2) return PT_OK;
+    if (n < 2 || (ctx->accel == PT_ACCEL_AUTO && n < BVH_AUTO_MIN_TRIANGLES)) return PT_OK;
     if (n > BVH_MAX_LEAVES) {
         if (ctx->accel == PT_ACCEL_AUTO) return PT_OK;           // the scan has no such limit
         return fail(ctx, PT_E_LIMIT, "%d triangles exceed the hierarchy's maximum of %d", n, BVH_MAX_LEAVES);
@@ -342,6 +346,9 @@ int with_variant(bool fast, int kind, F &&f)
     return f.template operator()<false, SCENE_BVH>();
 }
 
+// Surfaces every segment scans linearly: all of them, or those outside the hierarchy.
+static double ctx_scan_count(const pt_ctx *ctx) { return ctx->n_bvh > 0 ? ctx->n_loose : ctx->n_surfaces; }
+
 template <bool FAST, int KIND>
 int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample, uint64_t seed)
 {
@@ -405,19 +412,21 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
     P.chunk_len = chunk_len;
     P.n_pixels = n_pixels;
     P.n_items = (uint32_t)n_items64;
-    // Items a wave takes per atomic on the queue head: about 256 samples' worth.  Every wave of
-    // the launch adds to that one word, which takes some 140 adds per microsecond; with one-sample
-    // items (launches of a few samples per pixel) batches of 64 ask for more than that
-    // (800x800, 16 spp: 2046 us; with 256: 912 us), while large batches of large items
-    // leave the last waves with too much (1024 spp: 64 items 41.7 ms, 256 items 43.8 ms).
-    // (A hierarchy scene spends far longer per item: no pressure on the queue head, and the
-    // smaller batch ends sooner, 12.6 against 13.3 ms on the million-triangle field at 16 spp.)
+    // Items a wave takes per atomic on the queue head.  Every wave of the launch adds to that
+    // one word, which takes some 140 adds per microsecond; the batch is sized for about 40 at
+    // the rate this scene is expected to consume samples (samples per microsecond, from what
+    // a segment costs: the surfaces scanned and the depth of the hierarchy; 15 700 measured on
+    // the 8-surface headline scene, 3 200 on 85 surfaces, 2 200 on the million-triangle field).
+    // One-sample items in batches of 64 asked for more than the word can take (800x800 at
+    // 16 spp: 2046 us, now 912 us; a hierarchy over 18 triangles at 8 spp 1.13 -> 0.58 ms),
+    // while batches larger than needed leave the last waves with too much (1024 spp: 64 items
+    // 41.7 ms, 256 items 43.8 ms; the million-triangle field at 4 spp 1.99 -> 2.23 ms).
     // And never so many that a launch of few items feeds only some of its waves (356x200 at
     // 1 spp is 71k items for 1024 waves: 143 us with batches of 256, 121 us with 69).
+    const double samples_per_us = 2.5e5 / (8.0 + ctx_scan_count(ctx) + 6.0 * std::log2((double)ctx->n_bvh + 1.0));
     const uint64_t fair = n_items64 / (lanes / 64);
-    P.pool_batch = (uint32_t)std::min<uint64_t>((256u + chunk_len - 1) / chunk_len, fair);
+    P.pool_batch = (uint32_t)std::min<uint64_t>((uint64_t)(samples_per_us / (40.0 * chunk_len)), fair);
     P.pool_batch = std::min(std::max(P.pool_batch, POOL_BATCH_MIN), POOL_BATCH_MAX);
-    if constexpr (KIND == SCENE_BVH) P.pool_batch = POOL_BATCH_MIN;
     P.slabs = ctx->d_slabs;
     P.queue_head = ctx->d_queue;
     P.stats = reinterpret_cast<unsigned long long *>(ctx->d_queue + 2);

@@ -770,24 +770,36 @@ def test_soak_of_random_scenes_short():
 
 
 def test_scan_with_wave_level_early_outs_renders_like_the_oracle(ctx, pt, orc):
-    """249 surfaces: below the hierarchy's threshold, above the one at which the render kernel
-    asks the whole wave before finishing a surface's test; also bit-identical to the same
-    scene rendered through the hierarchy."""
+    """249 surfaces scanned linearly (PT_ACCEL_NONE): enough for the render kernel that asks the
+    whole wave before finishing a surface's test; also bit-identical to the same scene rendered
+    through the hierarchy, which PT_ACCEL_AUTO picks for it."""
     sc = pt.builtin_scene("heightfield:11", 120, 90)
     assert len(sc.surfaces) == 2 * 11 * 11 + 7
     osc = as_oracle_scene(orc, sc)
-    acc, cnt = render(ctx, pt, sc, 6, seed=12)
-    assert cnt.accel == pt.ACCEL_NONE
-    oacc, ocnt = orc.render(osc, 6, seed=12, threads=8)
-    frac = np.isclose(acc, oacc, rtol=2e-3, atol=2e-3).all(axis=2).mean()
-    assert frac >= 0.97 and abs(cnt.segments - ocnt.segments) <= 0.01 * ocnt.segments
     try:
-        ctx.set_accel(pt.ACCEL_BVH)
+        ctx.set_accel(pt.ACCEL_NONE)
+        acc, cnt = render(ctx, pt, sc, 6, seed=12)
+        assert cnt.accel == pt.ACCEL_NONE
+        oacc, ocnt = orc.render(osc, 6, seed=12, threads=8)
+        frac = np.isclose(acc, oacc, rtol=2e-3, atol=2e-3).all(axis=2).mean()
+        assert frac >= 0.97 and abs(cnt.segments - ocnt.segments) <= 0.01 * ocnt.segments
+        ctx.set_accel(pt.ACCEL_AUTO)
         via_bvh, bcnt = render(ctx, pt, sc, 6, seed=12)
         assert bcnt.accel == pt.ACCEL_BVH and bcnt.segments == cnt.segments
         assert np.array_equal(via_bvh, acc)
     finally:
         ctx.set_accel(pt.ACCEL_AUTO)
+
+
+def test_auto_picks_the_hierarchy_from_sixteen_small_triangles(ctx, pt):
+    """PT_ACCEL_AUTO: 8 small triangles are scanned, 18 go into a hierarchy; large triangles
+    (walls) never count."""
+    for quads, want in ((2, pt.ACCEL_NONE), (3, pt.ACCEL_BVH)):
+        sc = pt.builtin_scene("heightfield:%d" % quads, 64, 48)
+        _, cnt = render(ctx, pt, sc, 1)
+        assert cnt.accel == want, quads
+    _, cnt = render(ctx, pt, pt.builtin_scene("cornell", 64, 48), 1)      # 15 large triangles
+    assert cnt.accel == pt.ACCEL_NONE
 
 
 def test_scan_by_runs_of_one_kind_on_interleaved_kinds(ctx, pt, orc):

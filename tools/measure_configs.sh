@@ -18,6 +18,7 @@ run orange --scene orange_plane --size 1600 1600 --spp 128 --steps 5 --warmup 1
 run hf64 --scene heightfield --size 800 800 --spp 64 --steps 5 --warmup 2
 run hf16 --scene heightfield --size 800 800 --spp 16 --steps 5 --warmup 2
 run hf16_wf --scene heightfield --size 800 800 --spp 16 --steps 3 --warmup 1 --layout wavefront
+run hf11_scan --scene heightfield:11 --size 800 800 --spp 64 --steps 5 --warmup 1 --accel none
 run hf11 --scene heightfield:11 --size 800 800 --spp 64 --steps 5 --warmup 1
 run glass800 --scene glass_stress --size 800 800 --spp 256 --steps 5 --warmup 1
 run glass4k --scene glass_stress --size 3840 2160 --spp 4096 --steps 2 --warmup 1
