@@ -196,7 +196,9 @@ k_bvh_leaves(const unsigned long long *keys, int n, const float *geom, const int
 
 // Entry parameter of the ray into a box, or a negative value if it misses or
 // the box lies wholly beyond t_far.  inv = 1/d per component; slack widens the
-// test by the ray's own rounding (BvhCursor::slack).
+// test by the ray's own rounding (BvhCursor::slack).  (Slab crossings as one fused
+// b * inv - o * inv each: 1 % faster, and wrong where b * inv overflows but (b - o) * inv does
+// not; not kept.)
 PT_DEV float box_entry(float4 bmin, float4 bmax, V3 o, V3 inv, float t_far, float slack)
 {
     const float x1 = (bmin.x - o.x) * inv.x, x2 = (bmax.x - o.x) * inv.x;
