@@ -435,6 +435,7 @@ PT_DEV Hit closest_direct(cfloat_p geom, int n_surfaces, V3 o, V3 d, const int *
 constexpr float BAND_LO_REJ = -1.00001e-5f, BAND_LO_ACC = -0.99999e-5f;   // round -EPSILON
 constexpr float BAND_T_REJ = 0.99999e-5f, BAND_T_ACC = 1.00001e-5f;       // round +EPSILON
 constexpr float BAND_ONE_REJ = 1.0f + 2e-6f, BAND_ONE_ACC = 1.0f - 2e-6f; // round 1
+constexpr float BAND_SUM_ACC = BAND_ONE_ACC - 1.1e-5f;                    // u + v, standing for u < 1 as well
 constexpr float TRI_DIST_ERR = 2e-6f, SPH_DIST_ERR = 4e-7f;
 
 // Lanes whose x compares with the constant K as named, as a wave mask.  The
@@ -548,9 +549,10 @@ PT_DEV void scan_surface(Scan &st, int i, const GeomRec &rec, V3 o, V3 d)
             rej = or_lt<f32_bits(BAND_LO_REJ)>(det_bad, low_uv);
             rej = or_gt<f32_bits(BAND_ONE_REJ)>(rej, __builtin_fmaxf(u, s));
             rej = or_lt<f32_bits(BAND_T_REJ)>(rej, t);
+            // (u < 1 needs no test of its own: with v above -1e-5, u is below s + 1.00001e-5
+            // plus a rounding of s, and s is held that much farther from 1)
             acc = gt_andn<f32_bits(BAND_LO_ACC)>(det_bad, low_uv);
-            acc = and_lt<f32_bits(BAND_ONE_ACC)>(acc, u);
-            acc = and_lt<f32_bits(BAND_ONE_ACC)>(acc, s);
+            acc = and_lt<f32_bits(BAND_SUM_ACC)>(acc, s);
             acc = and_gt<f32_bits(BAND_T_ACC)>(acc, t);
             c_lo = dist * (1.0f - TRI_DIST_ERR);
             c_hi = dist * (1.0f + TRI_DIST_ERR);
