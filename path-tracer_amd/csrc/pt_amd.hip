@@ -78,6 +78,7 @@ struct pt_ctx {
     int n_bvh = 0, n_loose = 0;
     float bvh_ray_reach = 0.0f;
     int *d_loose = nullptr;
+    float *d_loose_geom = nullptr;
     std::vector<pt_surface> host_surfaces;      // kept to rebuild when pt_set_accel changes
     float4 *d_bvh_nodes = nullptr;
     float *d_bvh_leaves = nullptr;
@@ -184,8 +185,10 @@ constexpr int WAVE_SKIP_MIN_SPHERES = 16, WAVE_SKIP_MIN_TRIANGLES = 32;
 int build_hierarchy(pt_ctx *ctx, const pt_surface *surfaces, int n_surfaces)
 {
     if (ctx->d_loose) (void)hipFree(ctx->d_loose);
+    if (ctx->d_loose_geom) (void)hipFree(ctx->d_loose_geom);
     if (ctx->d_bvh_nodes) (void)hipFree(ctx->d_bvh_nodes);      // the leaves live in the same allocation
     ctx->d_loose = nullptr;
+    ctx->d_loose_geom = nullptr;
     ctx->d_bvh_nodes = nullptr;
     ctx->d_bvh_leaves = nullptr;
     ctx->n_bvh = ctx->n_loose = 0;
@@ -274,8 +277,20 @@ int build_hierarchy(pt_ctx *ctx, const pt_surface *surfaces, int n_surfaces)
     if ((rc = dev_alloc(ctx, &ctx->d_bvh_nodes, (size_t)2 * n * BVH_NODE_QUADS))) return rc;
     ctx->d_bvh_leaves = reinterpret_cast<float *>(ctx->d_bvh_nodes + (size_t)n * BVH_NODE_QUADS);
     if ((rc = dev_alloc(ctx, &ctx->d_loose, std::max<size_t>(loose.size(), 1)))) return rc;
-    if (!loose.empty())
+    if ((rc = dev_alloc(ctx, &ctx->d_loose_geom, std::max<size_t>(loose.size(), 1) * GEOM_STRIDE))) return rc;
+    Scratch<int> d_loose_runs;
+    std::vector<int> loose_runs(loose.size());
+    if (!loose.empty()) {
+        for (int j = (int)loose.size() - 1, run = 0; j >= 0; j--) {
+            run = (j + 1 < (int)loose.size() && surfaces[loose[j + 1]].kind == surfaces[loose[j]].kind) ? run + 1 : 1;
+            loose_runs[j] = run;
+        }
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_loose, loose.data(), loose.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = upload(ctx, d_loose_runs, loose_runs.data(), loose_runs.size()))) return rc;
+        hipLaunchKernelGGL(k_bvh_gather_loose, dim3((unsigned)((loose.size() + 255) / 256)), dim3(256), 0, ctx->stream,
+                           ctx->d_geom, ctx->d_loose, d_loose_runs.p, (int)loose.size(), ctx->d_loose_geom);
+        HIP_TRY(ctx, hipGetLastError());
+    }
 
     const unsigned blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_bvh_prepare, dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_geom, d_inside.p, n, gmin, ginv,
@@ -310,6 +325,7 @@ SceneView scene_view(const pt_ctx *ctx)
     v.n_surfaces = ctx->n_surfaces;
     v.n_scan = ctx->n_bvh > 0 ? ctx->n_loose : ctx->n_surfaces;
     v.loose = ctx->d_loose;
+    v.loose_geom = ctx->d_loose_geom;
     v.bvh.nodes = ctx->d_bvh_nodes;
     v.bvh.leaves = ctx->d_bvh_leaves;
     v.bvh.n_leaves = ctx->n_bvh;
@@ -659,6 +675,7 @@ void pt_destroy(pt_ctx *ctx)
     if (ctx->d_geom) (void)hipFree(ctx->d_geom);
     if (ctx->d_shade) (void)hipFree(ctx->d_shade);
     if (ctx->d_loose) (void)hipFree(ctx->d_loose);
+    if (ctx->d_loose_geom) (void)hipFree(ctx->d_loose_geom);
     if (ctx->d_bvh_nodes) (void)hipFree(ctx->d_bvh_nodes);      // the leaves live in the same allocation
     if (ctx->d_accum) (void)hipFree(ctx->d_accum);
     if (ctx->h_mapped) (void)hipHostFree(ctx->h_mapped);

@@ -192,6 +192,19 @@ k_bvh_leaves(const unsigned long long *keys, int n, const float *geom, const int
     dst[0] = a; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
 }
 
+// The geometry records of the surfaces outside the hierarchy, copied out in scan order,
+// with the run lengths of that order (GEOM_RUN).  One thread per record.
+__global__ void __launch_bounds__(256)
+k_bvh_gather_loose(const float *geom, const int *loose, const int *runs, int n, float *out)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const float4 *src = reinterpret_cast<const float4 *>(geom + (size_t)loose[j] * GEOM_STRIDE);
+    float4 *dst = reinterpret_cast<float4 *>(out + (size_t)j * GEOM_STRIDE);
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+    dst[3] = make_float4(__int_as_float(runs[j]), 0.0f, 0.0f, 0.0f);
+}
+
 // ---------------------------------------------------------------- traversal
 
 // Entry parameter of the ray into a box, or a negative value if it misses or

@@ -27,6 +27,8 @@ struct SceneView {
     int n_scan;               // surfaces scanned linearly
     int n_surfaces;           // surfaces in the scene
     const int *loose;         // with a hierarchy: the n_scan scene indices to scan, ascending
+    const float *loose_geom;  // and their geometry records, copied out in that order (a scan of
+                              // consecutive records: no look-up of an index before each one)
     BvhView bvh;
     float bg[3];
 };
@@ -45,7 +47,8 @@ PT_DEV Hit closest_hit(const SceneView &sc, V3 o, V3 d, float *lds, unsigned lon
     if constexpr (KIND != SCENE_BVH) {
         return closest_intersection<FAST, NEED_DIST, WAVE_SKIP>(as_constant(sc.geom), sc.n_scan, o, d, redo_count);
     } else {
-        Hit h = closest_intersection<FAST, true>(as_constant(sc.geom), sc.n_scan, o, d, redo_count, sc.loose);
+        Hit h = closest_intersection<FAST, true>(as_constant(sc.loose_geom), sc.n_scan, o, d, redo_count);
+        if (h.idx >= 0) h.idx = sc.loose[h.idx];
         if constexpr (BVH_STACK_IN_LDS) {
             closest_in_bvh<FAST>(sc.bvh, sc.geom, sc.n_surfaces, o, d, h,
                                  reinterpret_cast<int *>(lds) + threadIdx.x, BLOCK);
@@ -539,8 +542,9 @@ k_render_mega_bvh(RenderParams P)
             if (waits && alive) {
                 if (need_path) path_begin(ps, P.cam, it.pixel_key, it.s, it.px, it.py);
                 // the surfaces outside the hierarchy first, then the hierarchy
-                const Hit outside = closest_intersection<FAST, true>(as_constant(P.scene.geom), P.scene.n_scan,
-                                                                     ps.o, ps.d, P.stats + 1, P.scene.loose);
+                Hit outside = closest_intersection<FAST, true>(as_constant(P.scene.loose_geom), P.scene.n_scan,
+                                                               ps.o, ps.d, P.stats + 1);
+                if (outside.idx >= 0) outside.idx = P.scene.loose[outside.idx];
                 bvh_begin<FAST>(cur, P.scene.bvh, ps.o, ps.d, outside);
                 best = bvh_best_from<FAST>(outside);
                 traversing = true;
