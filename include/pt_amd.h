@@ -108,6 +108,11 @@ typedef struct pt_ctx pt_ctx;
 
 #define PT_MAX_DEPTH 1024      /* safety cap on path length; the reference has none */
 
+/* Bytes of the static device area pt_render_into_static works in: 256 for the work
+ * queue, the rest for partial sums of 12 bytes per pixel and chunk of samples, so an
+ * image may have at most (PT_STATIC_SCRATCH_BYTES - 256) / 12 = 2 796 181 pixels. */
+#define PT_STATIC_SCRATCH_BYTES (32u << 20)
+
 /* Library-wide: message for a failed pt_create (no context exists yet). */
 const char *pt_global_error(void);
 
@@ -157,6 +162,22 @@ int pt_render(pt_ctx *ctx, uint32_t spp, uint32_t first_sample, uint64_t seed, i
  * memory (for instance to reduce it across GPUs). */
 int pt_render_into(pt_ctx *ctx, float *accum_device, uint32_t spp, uint32_t first_sample,
                    uint64_t seed, int mode);
+
+/* pt_render_into for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in
+ * the reference.  Same arguments and the same image; the megakernel's work queue and
+ * the work items' partial sums live in a static device array of
+ * PT_STATIC_SCRATCH_BYTES that every GPU the library has a context on holds until the
+ * process ends, and the call makes no hipMalloc, hipFree or other allocating call.
+ * PT_E_LIMIT for an image of more pixels than the area holds one partial sum for;
+ * PT_E_INVALID for PT_MODE_WAVEFRONT (that layout allocates its path state).  With
+ * less room than pt_render_into would take, samples are cut into fewer, longer
+ * chunks: the sums then differ from pt_render_into's by the order of fp32 additions
+ * only (equal bit for bit when both cut alike, as for small images).  All calls on a
+ * GPU share that GPU's area: calls that overlap on one GPU, from any context or
+ * stream, race; pt_get_counters after the call reads the area too. */
+int pt_render_into_static(pt_ctx *ctx, float *accum_device, uint32_t spp, uint32_t first_sample,
+                          uint64_t seed, int mode);
 
 /* Copies the accumulation buffer (BUFFER, src/main.cpp:31, as running sums)
  * to host memory, height*width*3 floats row-major, and the sample counter.

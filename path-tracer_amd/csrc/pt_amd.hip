@@ -14,6 +14,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -21,9 +22,23 @@
 
 using namespace ptd;
 
+// Device memory for pt_render_into_static, the entry point that allocates nothing: the
+// work queue's words in the first STATIC_HEADER_BYTES, the work items' partial sums after
+// them.  Every GPU the library runs on holds its own copy, at its own address, until the
+// process ends.  Host code never uses the array's name as an address (on the host it is
+// a stand-in for the symbol): pt_create asks the runtime for the device address once per
+// device and everything below goes through that pointer.
+constexpr size_t STATIC_SCRATCH_BYTES = PT_STATIC_SCRATCH_BYTES;
+constexpr size_t STATIC_HEADER_BYTES = 256;
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+
 namespace {
 
 thread_local std::string g_error;
+
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+unsigned char *g_scratch_ptr[MAX_DEVICES];      // per device: where its copy of `scratch` lives
 
 struct HostV3 { float x, y, z; };
 inline HostV3 hsub(HostV3 a, HostV3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -92,6 +107,7 @@ struct pt_ctx {
     float *d_slabs = nullptr;        // partial sums of the work items
     size_t slab_floats = 0;
     uint32_t *d_queue = nullptr;     // [0] work counter; [2..3], [4..5]: 64-bit segment and redo counters
+    const uint32_t *last_queue = nullptr;   // the queue words the last render counted in (d_queue or the static scratch)
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 
     // wavefront layout: two sets of path-state arrays, per-path results, live counts
@@ -365,8 +381,17 @@ int with_variant(bool fast, int kind, F &&f)
 // Surfaces every segment scans linearly: all of them, or those outside the hierarchy.
 static double ctx_scan_count(const pt_ctx *ctx) { return ctx->n_bvh > 0 ? ctx->n_loose : ctx->n_surfaces; }
 
+// Where a render keeps its work queue and the work items' partial sums: the context's own
+// buffers (the partial sums grow on demand), or a fixed area the call may not outgrow.
+struct Workspace {
+    uint32_t *queue = nullptr;      // 8 words, zeroed before every launch
+    float *slabs = nullptr;         // fixed area: room for slab_floats partial sums
+    size_t slab_floats = 0;
+    bool fixed = false;             // false: ctx->d_queue and ctx->d_slabs
+};
+
 template <bool FAST, int KIND>
-int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample, uint64_t seed)
+int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample, uint64_t seed, Workspace ws)
 {
     const uint32_t n_pixels = (uint32_t)ctx->cam.width * (uint32_t)ctx->cam.height;
     const size_t lds_bytes = lds_bytes_for(ctx, KIND);
@@ -402,6 +427,14 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
     // little, but no more chunks than samples.  (Headline launch: 8 per lane 47.3 ms,
     // 16: 44.6, 32: 44.0, 64: 43.8 with twice the partial sums again.)
     uint64_t want_chunks = (32 * lanes + n_pixels - 1) / n_pixels;
+    if (ws.fixed) {
+        // a fixed area holds so many chunks of partial sums and no more
+        const uint64_t room = ws.slab_floats / ((uint64_t)n_pixels * 3);
+        if (room < 1)
+            return fail(ctx, PT_E_LIMIT, "image of %u pixels exceeds the static scratch area (%zu bytes hold %zu pixels)",
+                        n_pixels, STATIC_SCRATCH_BYTES, (STATIC_SCRATCH_BYTES - STATIC_HEADER_BYTES) / 12);
+        want_chunks = std::min(want_chunks, room);
+    }
     uint32_t n_chunks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want_chunks, 1), spp);
     const uint32_t chunk_len = (spp + n_chunks - 1) / n_chunks;
     n_chunks = (spp + chunk_len - 1) / chunk_len;
@@ -410,13 +443,19 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
         return fail(ctx, PT_E_LIMIT, "%llu work items exceed the 32-bit queue", (unsigned long long)n_items64);
 
     const size_t need = (size_t)n_items64 * 3;
-    if (need > ctx->slab_floats) {
-        if (ctx->d_slabs) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_slabs); }
-        ctx->d_slabs = nullptr;
-        ctx->slab_floats = 0;
-        int rc = dev_alloc(ctx, &ctx->d_slabs, need);
-        if (rc) return rc;
-        ctx->slab_floats = need;
+    if (ws.fixed) {
+        if (need > ws.slab_floats) return fail(ctx, PT_E_LIMIT, "partial sums exceed the static scratch area");
+    } else {
+        if (need > ctx->slab_floats) {
+            if (ctx->d_slabs) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_slabs); }
+            ctx->d_slabs = nullptr;
+            ctx->slab_floats = 0;
+            int rc = dev_alloc(ctx, &ctx->d_slabs, need);
+            if (rc) return rc;
+            ctx->slab_floats = need;
+        }
+        ws.queue = ctx->d_queue;
+        ws.slabs = ctx->d_slabs;
     }
 
     RenderParams P{};
@@ -443,18 +482,19 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
     const uint64_t fair = n_items64 / (lanes / 64);
     P.pool_batch = (uint32_t)std::min<uint64_t>((uint64_t)(samples_per_us / (40.0 * chunk_len)), fair);
     P.pool_batch = std::min(std::max(P.pool_batch, POOL_BATCH_MIN), POOL_BATCH_MAX);
-    P.slabs = ctx->d_slabs;
-    P.queue_head = ctx->d_queue;
-    P.stats = reinterpret_cast<unsigned long long *>(ctx->d_queue + 2);
+    P.slabs = ws.slabs;
+    P.queue_head = ws.queue;
+    P.stats = reinterpret_cast<unsigned long long *>(ws.queue + 2);
+    ctx->last_queue = ws.queue;
 
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 32, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ws.queue, 0, 32, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), lds_bytes, ctx->stream, P);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     const size_t n = (size_t)n_pixels * 3;
     hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks_for((long long)n)), dim3(BLOCK), 0, ctx->stream,
-                       ctx->d_slabs, n_chunks, n, accum);
+                       ws.slabs, n_chunks, n, accum);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
 
@@ -528,6 +568,7 @@ int launch_wavefront(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sam
     const size_t lds_bytes = lds_bytes_for(ctx, KIND);
     std::vector<uint32_t> counts(WF_COUNT_WORDS);
 
+    ctx->last_queue = ctx->d_queue;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 32, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     uint64_t segments = 0;
@@ -607,26 +648,31 @@ int guarded(pt_ctx *ctx, F &&f)
     }
 }
 
-int render_dispatch_body(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample, uint64_t seed, int mode);
+int render_dispatch_body(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample, uint64_t seed, int mode,
+                         Workspace ws);
 
-int render_dispatch(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample, uint64_t seed, int mode)
+int render_dispatch(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample, uint64_t seed, int mode,
+                    Workspace ws = Workspace{})
 {
-    return guarded(ctx, [&] { return render_dispatch_body(ctx, accum, spp, first_sample, seed, mode); });
+    return guarded(ctx, [&] { return render_dispatch_body(ctx, accum, spp, first_sample, seed, mode, ws); });
 }
 
-int render_dispatch_body(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample, uint64_t seed, int mode)
+int render_dispatch_body(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample, uint64_t seed, int mode,
+                         Workspace ws)
 {
     if (spp == 0) return fail(ctx, PT_E_INVALID, "spp must be positive");
     if ((uint64_t)first_sample + spp > 0xFFFFFFFFull)
         return fail(ctx, PT_E_LIMIT, "sample numbers must fit in 32 bits");
     if (mode & ~(PT_MODE_WAVEFRONT | PT_NUM_FAST)) return fail(ctx, PT_E_INVALID, "unknown mode bits 0x%x", mode);
     const bool fast = (mode & PT_NUM_FAST) != 0;
-    if (mode & PT_MODE_WAVEFRONT)
+    if (mode & PT_MODE_WAVEFRONT) {
+        if (ws.fixed) return fail(ctx, PT_E_INVALID, "the wavefront layout allocates its path state: megakernel only");
         return with_variant(fast, scene_kind(ctx), [&]<bool FAST, int KIND>() {
             return launch_wavefront<FAST, KIND>(ctx, accum, spp, first_sample, seed);
         });
+    }
     return with_variant(fast, scene_kind(ctx), [&]<bool FAST, int KIND>() {
-        return launch_render<FAST, KIND>(ctx, accum, spp, first_sample, seed);
+        return launch_render<FAST, KIND>(ctx, accum, spp, first_sample, seed, ws);
     });
 }
 
@@ -653,6 +699,15 @@ int pt_create(int device, pt_ctx **out)
     if (e == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
         delete ctx;
         return fail(nullptr, PT_E_HIP, "device %d is %s; this library holds gfx950 code only", device, prop.gcnArchName);
+    }
+    if (e == hipSuccess && device < MAX_DEVICES) {
+        // this device's copy of the static scratch area: asked for once, with the device current
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[device]) {
+            void *p = nullptr;
+            e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+            if (e == hipSuccess) g_scratch_ptr[device] = static_cast<unsigned char *>(p);
+        }
     }
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_queue, 32);
     for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipEventCreate(&ctx->ev[i]);
@@ -844,11 +899,9 @@ int pt_render(pt_ctx *ctx, uint32_t spp, uint32_t first_sample, uint64_t seed, i
     return rc;
 }
 
-int pt_render_into(pt_ctx *ctx, float *accum_device, uint32_t spp, uint32_t first_sample,
-                   uint64_t seed, int mode)
+// A caller-owned image must be device memory of the context's GPU.
+static int check_accum_device(pt_ctx *ctx, const float *accum_device)
 {
-    int rc = check_ready(ctx, true);
-    if (rc) return rc;
     if (!accum_device) return fail(ctx, PT_E_INVALID, "accum_device is null");
     hipPointerAttribute_t pa{};
     if (hipPointerGetAttributes(&pa, accum_device) != hipSuccess || pa.type != hipMemoryTypeDevice) {
@@ -857,7 +910,35 @@ int pt_render_into(pt_ctx *ctx, float *accum_device, uint32_t spp, uint32_t firs
     }
     if (pa.device != ctx->device)
         return fail(ctx, PT_E_INVALID, "accum_device lives on device %d, the context on %d", pa.device, ctx->device);
+    return PT_OK;
+}
+
+int pt_render_into(pt_ctx *ctx, float *accum_device, uint32_t spp, uint32_t first_sample,
+                   uint64_t seed, int mode)
+{
+    int rc = check_ready(ctx, true);
+    if (rc) return rc;
+    if ((rc = check_accum_device(ctx, accum_device))) return rc;
     return render_dispatch(ctx, accum_device, spp, first_sample, seed, mode);
+}
+
+int pt_render_into_static(pt_ctx *ctx, float *accum_device, uint32_t spp, uint32_t first_sample,
+                          uint64_t seed, int mode)
+{
+    int rc = check_ready(ctx, true);
+    if (rc) return rc;
+    if ((rc = check_accum_device(ctx, accum_device))) return rc;
+    unsigned char *area = ctx->device < MAX_DEVICES ? g_scratch_ptr[ctx->device] : nullptr;
+    if (!area) return fail(ctx, PT_E_INVALID, "device %d has no static scratch area", ctx->device);
+    if ((uint64_t)ctx->cam.width * ctx->cam.height > (STATIC_SCRATCH_BYTES - STATIC_HEADER_BYTES) / 12)
+        return fail(ctx, PT_E_LIMIT, "image %d x %d exceeds the static scratch area (%zu bytes hold %zu pixels)",
+                    ctx->cam.width, ctx->cam.height, STATIC_SCRATCH_BYTES, (STATIC_SCRATCH_BYTES - STATIC_HEADER_BYTES) / 12);
+    Workspace ws;
+    ws.fixed = true;
+    ws.queue = reinterpret_cast<uint32_t *>(area);
+    ws.slabs = reinterpret_cast<float *>(area + STATIC_HEADER_BYTES);
+    ws.slab_floats = (STATIC_SCRATCH_BYTES - STATIC_HEADER_BYTES) / sizeof(float);
+    return render_dispatch(ctx, accum_device, spp, first_sample, seed, mode, ws);
 }
 
 int pt_read_accum(pt_ctx *ctx, float *rgb_sum_host, uint64_t *total_samples)
@@ -1152,7 +1233,7 @@ int pt_get_counters(pt_ctx *ctx, pt_counters *out)
         HIP_TRY(ctx, hipEventElapsedTime(&ms_kernel, ctx->ev[0], ctx->ev[1]));
         HIP_TRY(ctx, hipEventElapsedTime(&ms_total, ctx->ev[0], ctx->ev[2]));
         unsigned long long st[2] = {0, 0};
-        HIP_TRY(ctx, hipMemcpy(st, ctx->d_queue + 2, 16, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(st, ctx->last_queue + 2, 16, hipMemcpyDeviceToHost));
         const unsigned long long seg = st[0];
         ctx->last.segments = seg;
         ctx->last.redone = st[1];

@@ -26,6 +26,7 @@ MODE_MEGAKERNEL, MODE_WAVEFRONT = 0x0, 0x1
 NUM_EXACT, NUM_FAST = 0x0, 0x10
 MAX_DEPTH = 1024
 ACCEL_AUTO, ACCEL_NONE, ACCEL_BVH, ACCEL_LDS_TILES = 0, 1, 2, 3
+STATIC_SCRATCH_BYTES = 32 << 20      # PT_STATIC_SCRATCH_BYTES
 
 SCENE_NAMES = ("dof_demo", "test", "orange_plane", "red_corner", "sunrise",
                "cornell_2", "cornell")
@@ -34,6 +35,7 @@ SCENE_NAMES = ("dof_demo", "test", "orange_plane", "red_corner", "sunrise",
 ABI_SYMBOLS = (
     "pt_global_error", "pt_create", "pt_destroy", "pt_last_error", "pt_set_stream",
     "pt_set_scene", "pt_set_accel", "pt_set_camera", "pt_clear", "pt_render", "pt_render_into",
+    "pt_render_into_static",
     "pt_read_accum", "pt_map_accum", "pt_write_accum", "pt_tonemap_rgb8", "pt_primary_hits", "pt_intersect_rays",
     "pt_camera_rays", "pt_eval_bsdf", "pt_eval_brdf", "pt_rng_uniform", "pt_get_counters",
 )
@@ -239,6 +241,12 @@ class Context:
         self._check(self._lib.pt_render_into(self._h, C.c_void_p(device_ptr), C.c_uint32(spp),
                                              C.c_uint32(first_sample), C.c_uint64(seed),
                                              C.c_int(mode)))
+
+    def render_into_static(self, device_ptr, spp, first_sample=0, seed=1, mode=0):
+        """render_into over the library's static device scratch area: allocates nothing."""
+        self._check(self._lib.pt_render_into_static(self._h, C.c_void_p(device_ptr), C.c_uint32(spp),
+                                                    C.c_uint32(first_sample), C.c_uint64(seed),
+                                                    C.c_int(mode)))
 
     def read_accum(self):
         out = np.empty((self.height, self.width, 3), dtype=np.float32)
