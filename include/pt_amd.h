@@ -139,6 +139,13 @@ int pt_set_scene(pt_ctx *ctx, const pt_surface *surfaces, int32_t n_surfaces,
  * distance as the scan, ties included. */
 int pt_set_accel(pt_ctx *ctx, int accel);
 
+/* Ends every path of later renders after max_segments closest-hit queries
+ * (1..PT_MAX_DEPTH; default PT_MAX_DEPTH).  trace_ray's loop (src/main.cpp:84) has no
+ * bound; the two Cornell-box images the reference ships (images/diffuse.png,
+ * images/cornell_800_276s.png) are reproduced with max_segments = 7, which is what this
+ * setting is for besides bounding the cost of a preview. */
+int pt_set_max_depth(pt_ctx *ctx, int max_segments);
+
 /* Uploads the camera and DOF state; (re)allocates the accumulation buffer
  * when the image size changes and clears it, as src/main.cpp:262-269 does
  * when the camera moved. */

@@ -1,8 +1,10 @@
 /*
  * pt_oracle.c -- CPU restatement of the reference path tracer's render step.
  *
- * TEST INFRASTRUCTURE ONLY (see pt_oracle.h).  PARITY UNPINNED: the reference
- * holds no tests or golden vectors for this path and cannot be built here.
+ * TEST INFRASTRUCTURE ONLY (see pt_oracle.h).  PARITY: pinned at image level
+ * by the five renders the reference ships (tests/test_reference_images.py);
+ * unpinned at bit level (GLM's operation order) - the reference holds no tests
+ * or golden vectors for this path and cannot be built here.
  *
  * Every routine cites the reference file:line it follows (paths relative to
  * the reference's root).  GLM is an un-vendored, un-pinned dependency of the
@@ -426,6 +428,12 @@ static inline double draw(rand_src *rs)
     return rs->libc ? random_real_libc(0, 1) : rng_next(&rs->rng);
 }
 
+/* Path-length cap of the next renders, in segments; 0 = none (the reference's loop,
+ * main.cpp:84, has none).  Set through orc_set_path_cap; see pt_oracle.h. */
+static int g_path_cap = 0;
+
+void orc_set_path_cap(int segments) { g_path_cap = segments > 0 ? segments : 0; }
+
 /* main.cpp:80-111 */
 static v3 trace_ray(const orc_scene *scene, v3 origin, v3 dir, rand_src *rs,
                     uint64_t *segments, uint64_t *max_depth)
@@ -454,6 +462,8 @@ static v3 trace_ray(const orc_scene *scene, v3 origin, v3 dir, rand_src *rs,
             throughput = mul(throughput, brdf(m->type, ld3(m->color), normal, new_dir));
             dir = new_dir;
 
+            if (g_path_cap && depth + 1 >= g_path_cap)   /* test knob, absent from the reference */
+                break;
             if (depth < 5)
                 continue;
             if (depth + 1 >= ORC_MAX_DEPTH)   /* safety cap, absent from the reference */

@@ -5,12 +5,19 @@
  * product: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
  * leg may load this library, and only as the checker.
  *
- * PARITY UNPINNED: the reference (jvgille/Path-Tracer) ships no tests, golden
- * vectors or fixtures for this path, and it cannot be built in this image (it
- * needs GLM and SDL 1.2, neither of which is present).  Every function below
- * restates the reference's algorithm from its source text, citing file:line,
- * with GLM's published scalar formulas for dot/cross/length/normalize/
- * determinant/mat3 products.
+ * PARITY: the reference (jvgille/Path-Tracer) ships no tests or golden vectors
+ * for this path, and it cannot be built in this image (it needs GLM and SDL
+ * 1.2, neither of which is present).  What it does ship are five images of its
+ * own renderer (images/*.png): this oracle reproduces them - silhouettes for
+ * 99.9 % of the pixels, block means within the images' own noise, mean levels
+ * to 0.02-0.3 of a grey level - tests/test_reference_images.py.  That pins
+ * camera, scene data, surface tests, samplers, weights and the tone map at
+ * image level.  UNPINNED remain: the bit-level operation order of GLM (no
+ * image can pin it; restated from GLM's published scalar formulas), and the
+ * energy of paths beyond their 7th segment (four of the five images were
+ * rendered by a revision that stopped paths there; see orc_set_path_cap).
+ * Every function below restates the reference's algorithm from its source
+ * text, citing file:line.
  *
  * Plain C, fp32 arithmetic with no fused multiply-add (build with
  * -ffp-contract=off and no -march: the reference's own x86-64 build has no
@@ -121,6 +128,14 @@ float orc_rng_uniform(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t d
  * on (seed, pixel = y*W+x, first_sample + s, draw index).  accum: H x W x 3
  * running sums, row-major, ADDED to.  Pixels are split over `threads` OpenMP
  * threads (1 = serial, as the reference runs).  counters may be NULL. */
+/* Stops every path of later renders after `segments` closest-hit queries (0 = no cap,
+ * the default and what the reference's source says, main.cpp:84).  A test knob: the two
+ * Cornell-box images the reference ships (images/diffuse.png, images/cornell_800_276s.png)
+ * are reproduced to within their own noise with a cap of 7 and not without one, so they
+ * were evidently rendered by a revision with a bounded path length
+ * (tests/test_reference_images.py).  Not thread-safe against a render in progress. */
+void orc_set_path_cap(int segments);
+
 void orc_render(const orc_scene *scene, const orc_camera *cam, uint32_t spp,
                 uint32_t first_sample, uint64_t seed, int threads,
                 float *accum, orc_counters *counters);

@@ -1,10 +1,11 @@
 """ctypes binding of the CPU oracle (oracle/pt_oracle.c).
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
-bench.py's cpu_baseline leg, never by the product package.  PARITY UNPINNED:
-the reference ships no fixtures for this path and cannot be built here, so the
-oracle is a restatement from the reference's source text (file:line cited in
-pt_oracle.c).
+bench.py's cpu_baseline leg, never by the product package.  PARITY: pinned at
+image level by the five renders the reference ships (tests/test_reference_images.py);
+unpinned at bit level (GLM's operation order): the reference holds no golden vectors for
+this path and cannot be built here, so the oracle is a restatement from the reference's
+source text (file:line cited in pt_oracle.c).
 """
 import ctypes as C
 import os
@@ -175,6 +176,11 @@ def render(scene, spp, first_sample=0, seed=1, threads=1, accum=None):
     lib().orc_render(C.byref(cs), _p(scene.camera), C.c_uint32(spp), C.c_uint32(first_sample),
                      C.c_uint64(seed), int(threads), _p(accum), C.byref(cnt))
     return accum, cnt
+
+
+def set_path_cap(segments):
+    """Paths of later renders stop after `segments` segments (0 = no cap, the default)."""
+    lib().orc_set_path_cap(int(segments))
 
 
 def render_libc_rand(scene, spp, seed=1, accum=None):

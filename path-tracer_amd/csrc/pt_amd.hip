@@ -90,6 +90,7 @@ struct pt_ctx {
 
     // hierarchy over the small triangles (n_bvh == 0: none) and the surfaces left outside it
     int accel = PT_ACCEL_AUTO;
+    int max_depth = PT_MAX_DEPTH;    // segments per path at most (pt_set_max_depth)
     int n_bvh = 0, n_loose = 0;
     float bvh_ray_reach = 0.0f;
     int *d_loose = nullptr;
@@ -347,6 +348,7 @@ SceneView scene_view(const pt_ctx *ctx)
     v.bvh.n_leaves = ctx->n_bvh;
     v.bvh.ray_reach = ctx->bvh_ray_reach;
     memcpy(v.bg, ctx->bg, sizeof v.bg);
+    v.max_depth = ctx->max_depth;
     return v;
 }
 
@@ -848,6 +850,15 @@ int pt_set_accel(pt_ctx *ctx, int accel)
     if (!ctx->have_scene) return PT_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return guarded(ctx, [&] { return build_hierarchy(ctx, ctx->host_surfaces.data(), ctx->n_surfaces); });
+}
+
+int pt_set_max_depth(pt_ctx *ctx, int max_segments)
+{
+    if (!ctx) return fail(nullptr, PT_E_INVALID, "null context");
+    if (max_segments < 1 || max_segments > PT_MAX_DEPTH)
+        return fail(ctx, PT_E_INVALID, "path length cap %d outside 1..%d", max_segments, PT_MAX_DEPTH);
+    ctx->max_depth = max_segments;
+    return PT_OK;
 }
 
 int pt_set_camera(pt_ctx *ctx, const pt_camera *cam)

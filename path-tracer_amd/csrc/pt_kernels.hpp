@@ -31,6 +31,7 @@ struct SceneView {
                               // consecutive records: no look-up of an index before each one)
     BvhView bvh;
     float bg[3];
+    int max_depth;            // a path ends after this many segments (1..MAX_DEPTH)
 };
 
 // Scene kinds a kernel is compiled for.
@@ -321,16 +322,14 @@ PT_DEV bool shade_hit(PathState &ps, const SceneView &sc, const float *shade, co
     ps.thr = ps.thr * brdf<true>(type, v3(r0.x, r0.y, r0.z), normal, new_dir);
     ps.d = new_dir;
     bool ended = false;
-    if (ps.depth >= 5) {                            // russian roulette, main.cpp:97-104
-        if (ps.depth + 1 >= MAX_DEPTH) {
-            ended = true;
-        } else {
-            float m = ps.thr.y < ps.thr.z ? ps.thr.z : ps.thr.y;
-            m = ps.thr.x < m ? m : ps.thr.x;
-            const float p = m < 0.0f ? 0.0f : (0.95f < m ? 0.95f : m);
-            if (rng_next(ps.rng) > p) ended = true;
-            else ps.thr = ps.thr * S::div(1.0f, p);
-        }
+    if (ps.depth + 1 >= sc.max_depth) {             // the cap on path length (the reference has none)
+        ended = true;
+    } else if (ps.depth >= 5) {                     // russian roulette, main.cpp:97-104
+        float m = ps.thr.y < ps.thr.z ? ps.thr.z : ps.thr.y;
+        m = ps.thr.x < m ? m : ps.thr.x;
+        const float p = m < 0.0f ? 0.0f : (0.95f < m ? 0.95f : m);
+        if (rng_next(ps.rng) > p) ended = true;
+        else ps.thr = ps.thr * S::div(1.0f, p);
     }
     ps.depth++;
     return ended;

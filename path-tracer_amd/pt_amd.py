@@ -34,7 +34,7 @@ SCENE_NAMES = ("dof_demo", "test", "orange_plane", "red_corner", "sunrise",
 # Every symbol include/pt_amd.h declares.
 ABI_SYMBOLS = (
     "pt_global_error", "pt_create", "pt_destroy", "pt_last_error", "pt_set_stream",
-    "pt_set_scene", "pt_set_accel", "pt_set_camera", "pt_clear", "pt_render", "pt_render_into",
+    "pt_set_scene", "pt_set_accel", "pt_set_max_depth", "pt_set_camera", "pt_clear", "pt_render", "pt_render_into",
     "pt_render_into_static",
     "pt_read_accum", "pt_map_accum", "pt_write_accum", "pt_tonemap_rgb8", "pt_primary_hits", "pt_intersect_rays",
     "pt_camera_rays", "pt_eval_bsdf", "pt_eval_brdf", "pt_rng_uniform", "pt_get_counters",
@@ -217,6 +217,9 @@ class Context:
 
     def set_accel(self, accel):
         self._check(self._lib.pt_set_accel(self._h, C.c_int(accel)))
+
+    def set_max_depth(self, max_segments):
+        self._check(self._lib.pt_set_max_depth(self._h, C.c_int(max_segments)))
 
     def set_camera(self, camera):
         camera = np.ascontiguousarray(camera, dtype=CAMERA).reshape(1)

@@ -230,6 +230,28 @@ def test_render_paths_match_oracle(ctx, pt, orc, name):
     assert cnt.tests == cnt.segments * len(pt.builtin_scene(name, w, h).surfaces)
 
 
+@pytest.mark.parametrize("cap", [1, 3, 7])
+def test_path_length_cap_matches_oracle(ctx, pt, orc, cap):
+    """pt_set_max_depth against the oracle's path cap: paths end after the same segment, so
+    segment counts agree and the images are path-matched as without a cap."""
+    w, h, spp = 96, 64, 4
+    sc = pt.builtin_scene("cornell_2", w, h)
+    ctx.set_max_depth(cap)
+    orc.set_path_cap(cap)
+    try:
+        acc, cnt = render(ctx, pt, sc, spp, seed=11)
+        oacc, ocnt = orc.render(orc.builtin_scene("cornell_2", w, h), spp, seed=11, threads=8)
+    finally:
+        ctx.set_max_depth(pt.MAX_DEPTH)
+        orc.set_path_cap(0)
+    assert cnt.segments <= cap * cnt.samples
+    assert abs(cnt.segments - ocnt.segments) <= 0.01 * ocnt.segments
+    assert np.isclose(acc, oacc, rtol=2e-3, atol=2e-3).all(axis=2).mean() >= 0.97
+    for bad in (0, -3, pt.MAX_DEPTH + 1):
+        with pytest.raises(pt.PtError):
+            ctx.set_max_depth(bad)
+
+
 @pytest.mark.parametrize("numeric", ["exact", "fast"])
 @pytest.mark.parametrize("name", ["cornell_2", "orange_plane", "cornell"])
 def test_converged_image_rmse(ctx, pt, golden, name, numeric):
