@@ -5,7 +5,9 @@
 One step = one pass of the hot path over one batch: `spp` samples per pixel of
 Scenes::cornell_2 at 800x800 (1024 spp, BASELINE.json configs[1]) rendered by
 the HIP megakernel through the C ABI into a device-resident accumulation
-buffer.  With N > 1 (one process per GPU, launched by torch.distributed.run)
+buffer.  With N > 1 (one process per GPU: under torch.distributed.run, or, when
+started plainly as `python bench.py --gpus N`, as N rank processes this script
+launches itself before it touches the GPU)
 every rank renders its own `spp` samples per step - disjoint global sample
 numbers, so the ranks' images add up to one (N*spp)-sample image - and the
 buffers are combined on rank 0 with one RCCL reduce per step (weak scaling).
@@ -109,8 +111,27 @@ def pmc_summary():
         return {}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` started by hand: runs the same command line as N rank
+    processes under torch.distributed.run (one per GPU, rendezvous on 127.0.0.1) as a child of
+    this process, which has not touched the GPU, and returns the child's exit code.  The
+    ranks' output (rank 0's JSON line) passes through."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be positive")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))
     import torch
     import torch.distributed as dist
     import pt_amd
@@ -120,8 +141,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run "
-                         "--nproc-per-node %d" % (args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("no GPU: the render step has no CPU fallback")
     # PT_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs

@@ -59,3 +59,11 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     check_contract(out, 2)
     assert "cpu_baseline" not in out
     assert "gloo" in out["config"]["parallelism"]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` started plainly, the way the round-end scaling run starts it:
+    the script spawns its two ranks itself (gloo here: both share the test box's one GPU)."""
+    out = run([sys.executable, "bench.py", "--gpus", "2"] + SMALL, env={"PT_BENCH_BACKEND": "gloo"})
+    check_contract(out, 2)
+    assert "gloo" in out["config"]["parallelism"]
