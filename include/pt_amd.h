@@ -252,6 +252,48 @@ int pt_rng_uniform(pt_ctx *ctx, uint64_t seed, const uint32_t *pixel, const uint
 /* Statistics of the last pt_render / pt_render_into (waits for it). */
 int pt_get_counters(pt_ctx *ctx, pt_counters *out);
 
+/* ---- several GPUs of one node ------------------------------------------------------
+ * No counterpart in the reference (one thread, one image).  A group owns one context per
+ * device; a render call's samples are partitioned by global sample number - device r of n
+ * renders samples [first + r*spp/n, first + (r+1)*spp/n) of every pixel - and the per-device
+ * running sums are combined on the group's first device by ONE ncclReduce (RCCL, loaded
+ * with dlopen when the first group is created).  Because a path's random stream depends
+ * only on (seed, pixel, sample number) and the image is a sum (src/main.cpp:139), the
+ * group's image equals one GPU's up to the order of fp32 additions.  One host thread
+ * drives a group; calls on a group must be serialised. */
+typedef struct pt_group pt_group;
+
+int  pt_group_create(const int *devices, int n_devices, pt_group **out);   /* distinct HIP ordinals */
+void pt_group_destroy(pt_group *g);
+const char *pt_group_last_error(pt_group *g);     /* g may be NULL after a failed create */
+int  pt_group_size(pt_group *g);
+/* Context of member i (0 = the device the image is combined on), for pt_get_counters and
+ * the parity entry points; do not set its stream, scene or camera directly. */
+pt_ctx *pt_group_context(pt_group *g, int i);
+/* The share of rank `rank` of `n` in samples [first_sample, first_sample + spp_total). */
+void pt_group_share(uint32_t spp_total, int n, int rank, uint32_t first_sample, uint32_t *first, uint32_t *count);
+
+/* pt_set_scene / pt_set_accel / pt_set_max_depth / pt_set_camera / pt_clear on every member
+ * (the scene is replicated; the camera call sizes and clears the per-device images). */
+int pt_group_set_scene(pt_group *g, const pt_surface *surfaces, int32_t n_surfaces,
+                       const pt_material *materials, int32_t n_materials, const float bg[3]);
+int pt_group_set_accel(pt_group *g, int accel);
+int pt_group_set_max_depth(pt_group *g, int max_segments);
+int pt_group_set_camera(pt_group *g, const pt_camera *cam);
+int pt_group_clear(pt_group *g);
+
+/* trace_rays (src/main.cpp:114-143) run spp_total times, shared among the devices: every
+ * member's launch is enqueued on its own stream; the call does not wait for them. */
+int pt_group_render(pt_group *g, uint32_t spp_total, uint32_t first_sample, uint64_t seed, int mode);
+/* The one collective: sums the members' images onto the first device (ncclReduce, fp32 sum,
+ * height*width*3 values: 7.68 MB at 800 x 800) and makes the result, with the sample count
+ * of all render calls since the last clear, the first context's accumulation buffer.  Waits. */
+int pt_group_reduce(pt_group *g);
+/* pt_read_accum / pt_tonemap_rgb8 of the combined image (reducing first when render calls
+ * have been made since the last reduce). */
+int pt_group_read_accum(pt_group *g, float *rgb_sum_host, uint64_t *total_samples);
+int pt_group_tonemap_rgb8(pt_group *g, uint8_t *out_host);
+
 #ifdef __cplusplus
 }
 #endif

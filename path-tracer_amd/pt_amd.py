@@ -38,6 +38,10 @@ ABI_SYMBOLS = (
     "pt_render_into_static",
     "pt_read_accum", "pt_map_accum", "pt_write_accum", "pt_tonemap_rgb8", "pt_primary_hits", "pt_intersect_rays",
     "pt_camera_rays", "pt_eval_bsdf", "pt_eval_brdf", "pt_rng_uniform", "pt_get_counters",
+    "pt_group_create", "pt_group_destroy", "pt_group_last_error", "pt_group_size", "pt_group_context",
+    "pt_group_share", "pt_group_set_scene", "pt_group_set_accel", "pt_group_set_max_depth",
+    "pt_group_set_camera", "pt_group_clear", "pt_group_render", "pt_group_reduce",
+    "pt_group_read_accum", "pt_group_tonemap_rgb8",
 )
 
 
@@ -73,9 +77,17 @@ def load():
         lib.pt_last_error.argtypes = [C.c_void_p]
         lib.pt_destroy.restype = None
         lib.pt_destroy.argtypes = [C.c_void_p]
+        lib.pt_group_last_error.restype = C.c_char_p
+        lib.pt_group_last_error.argtypes = [C.c_void_p]
+        lib.pt_group_destroy.restype = None
+        lib.pt_group_destroy.argtypes = [C.c_void_p]
+        lib.pt_group_context.restype = C.c_void_p
+        lib.pt_group_context.argtypes = [C.c_void_p, C.c_int]
+        lib.pt_group_share.restype = None
         for name in ABI_SYMBOLS:
             fn = getattr(lib, name)
-            if name not in ("pt_global_error", "pt_last_error", "pt_destroy"):
+            if name not in ("pt_global_error", "pt_last_error", "pt_destroy", "pt_group_last_error",
+                            "pt_group_destroy", "pt_group_context", "pt_group_share"):
                 fn.restype = C.c_int
         _lib = lib
     return _lib
@@ -344,4 +356,93 @@ class Context:
     def counters(self):
         c = Counters()
         self._check(self._lib.pt_get_counters(self._h, C.byref(c)))
+        return c
+
+
+def group_share(spp_total, n, rank, first_sample=0):
+    """pt_group_share: (first, count) of rank `rank` of `n`."""
+    first, count = C.c_uint32(0), C.c_uint32(0)
+    load().pt_group_share(C.c_uint32(spp_total), C.c_int(n), C.c_int(rank), C.c_uint32(first_sample),
+                          C.byref(first), C.byref(count))
+    return first.value, count.value
+
+
+class Group:
+    """Several GPUs of one node rendering one image (pt_group): samples partitioned by global
+    sample number, one RCCL reduce onto the first device."""
+
+    def __init__(self, devices):
+        self._lib = load()
+        self._h = C.c_void_p()
+        devs = (C.c_int * len(devices))(*devices)
+        rc = self._lib.pt_group_create(devs, C.c_int(len(devices)), C.byref(self._h))
+        if rc != 0:
+            raise PtError(rc, self._lib.pt_group_last_error(None).decode())
+        self.width = self.height = 0
+
+    def close(self):
+        if self._h:
+            self._lib.pt_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise PtError(rc, self._lib.pt_group_last_error(self._h).decode())
+
+    @property
+    def size(self):
+        return int(self._lib.pt_group_size(self._h))
+
+    def load(self, scene):
+        self._check(self._lib.pt_group_set_scene(self._h, _p(scene.surfaces), C.c_int32(len(scene.surfaces)),
+                                                 _p(scene.materials), C.c_int32(len(scene.materials)), _p(scene.bg)))
+        self._check(self._lib.pt_group_set_camera(self._h, _p(scene.camera)))
+        self.width, self.height = scene.width, scene.height
+        return self
+
+    def set_accel(self, accel):
+        self._check(self._lib.pt_group_set_accel(self._h, C.c_int(accel)))
+
+    def set_max_depth(self, max_segments):
+        self._check(self._lib.pt_group_set_max_depth(self._h, C.c_int(max_segments)))
+
+    def clear(self):
+        self._check(self._lib.pt_group_clear(self._h))
+
+    def render(self, spp_total, first_sample=0, seed=1, mode=0):
+        self._check(self._lib.pt_group_render(self._h, C.c_uint32(spp_total), C.c_uint32(first_sample),
+                                              C.c_uint64(seed), C.c_int(mode)))
+
+    def reduce(self):
+        self._check(self._lib.pt_group_reduce(self._h))
+
+    def read_accum(self):
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        total = C.c_uint64(0)
+        self._check(self._lib.pt_group_read_accum(self._h, _p(out), C.byref(total)))
+        return out, total.value
+
+    def tonemap_rgb8(self):
+        out = np.empty((self.height, self.width, 3), dtype=np.uint8)
+        self._check(self._lib.pt_group_tonemap_rgb8(self._h, _p(out)))
+        return out
+
+    def counters(self, member=0):
+        c = Counters()
+        h = self._lib.pt_group_context(self._h, C.c_int(member))
+        rc = self._lib.pt_get_counters(C.c_void_p(h), C.byref(c))
+        if rc != 0:
+            raise PtError(rc, self._lib.pt_last_error(C.c_void_p(h)).decode())
         return c
