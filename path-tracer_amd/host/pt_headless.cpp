@@ -4,12 +4,13 @@
 // reference's -exit stops at 100) and write the tone-mapped image as a PPM.
 //
 //   pt_headless [-scene NAME | -file SCENE.txt] [-width W] [-height H] [-passes N]
-//               [-batch B] [-fast] [-out FILE.ppm]
+//               [-batch B] [-gpus N] [-fast] [-out FILE.ppm]
 //               [-log] [-exit] [-keys SCRIPT] [-images DIR]
 //
 // -batch B > 0 renders B samples per pixel in one GPU call per pass through
 // pt::Renderer, keeping the sums on the device, instead of one sample per
-// trace_rays call.
+// trace_rays call.  -gpus N (with -batch) shares every pass's B samples among
+// devices 0..N-1 and combines their images with one RCCL reduce at the end.
 //
 // -log, -exit, -keys or -images select the interactive loop (pt_viewer.hpp)
 // with its window replaced by a replay script: -log saves DIR/<passes>.bmp at
@@ -44,7 +45,7 @@ static bool write_ppm(const std::string &path, int width, int height, const std:
 int main(int argc, char *argv[])
 {
     std::string scene_name = "orange_plane", scene_file, out;   // the reference's default scene (src/main.cpp:311)
-    int width = 356, height = 200, passes = 100, batch = 0;
+    int width = 356, height = 200, passes = 100, batch = 0, gpus = 0;
     bool fast = false, viewer = false, log_images = false, exit_at_target = false;
     std::string key_script, image_dir = "../images/";
     for (int i = 1; i < argc; i++) {
@@ -59,6 +60,7 @@ int main(int argc, char *argv[])
         else if (a == "-height") height = std::atoi(next("-height"));
         else if (a == "-passes") passes = std::atoi(next("-passes"));
         else if (a == "-batch") batch = std::atoi(next("-batch"));
+        else if (a == "-gpus") gpus = std::atoi(next("-gpus"));
         else if (a == "-out") out = next("-out");
         else if (a == "-fast") fast = true;
         else if (a == "-log") { viewer = log_images = true; }
@@ -67,7 +69,8 @@ int main(int argc, char *argv[])
         else if (a == "-images") { viewer = true; image_dir = next("-images"); if (!image_dir.empty() && image_dir.back() != '/') image_dir += '/'; }
         else { std::cerr << "unknown argument " << a << std::endl; return 2; }
     }
-    if (width < 1 || height < 1 || passes < 1 || batch < 0) { std::cerr << "bad size" << std::endl; return 2; }
+    if (width < 1 || height < 1 || passes < 1 || batch < 0 || gpus < 0) { std::cerr << "bad size" << std::endl; return 2; }
+    if (gpus > 0 && (batch == 0 || viewer)) { std::cerr << "-gpus needs -batch and no viewer loop" << std::endl; return 2; }
 
     try {
         set_screen_size(width, height);
@@ -149,7 +152,13 @@ int main(int argc, char *argv[])
                 rgb = r.tonemap();
             }
         } else {
-            pt::Renderer &r = pt::default_renderer();
+            std::optional<pt::Renderer> many;
+            if (gpus > 0) {
+                std::vector<int> devices;
+                for (int d = 0; d < gpus; d++) devices.push_back(d);
+                many.emplace(devices);
+            }
+            pt::Renderer &r = many ? *many : pt::default_renderer();
             r.sync(*scene, width, height);
             for (int pass = 0; pass < passes; pass++) {
                 r.render(static_cast<uint32_t>(batch), 1, fast ? PT_NUM_FAST : PT_NUM_EXACT);
@@ -162,8 +171,8 @@ int main(int argc, char *argv[])
         }
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         const double n = static_cast<double>(width) * height * TOTAL_SAMPLES;
-        std::printf("scene=%s size=%dx%d samples_per_pixel=%u seconds=%.3f Msamples_per_s=%.2f mean_rgb=%.6f,%.6f,%.6f\n",
-                    scene_name.c_str(), width, height, TOTAL_SAMPLES, secs, n / secs / 1e6,
+        std::printf("scene=%s size=%dx%d gpus=%d samples_per_pixel=%u seconds=%.3f Msamples_per_s=%.2f mean_rgb=%.6f,%.6f,%.6f\n",
+                    scene_name.c_str(), width, height, gpus > 0 ? gpus : 1, TOTAL_SAMPLES, secs, n / secs / 1e6,
                     mean[0] / n, mean[1] / n, mean[2] / n);
         if (!out.empty()) {
             if (!write_ppm(out, width, height, rgb)) { std::cerr << "cannot write " << out << std::endl; return 1; }

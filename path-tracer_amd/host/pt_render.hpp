@@ -91,9 +91,12 @@ inline FlatScene flatten(const Scene &scene, int width, int height)
     return f;
 }
 
-// RAII owner of one GPU context.
+// RAII owner of one GPU context, or of a group of them (several GPUs of one node rendering
+// one image: pt_group_* of the C ABI; samples are shared by sample number and the images
+// combined on the first device by one RCCL reduce whenever the sums are read).
 class Renderer {
-    pt_ctx *ctx_ = nullptr;
+    pt_ctx *ctx_ = nullptr;          // the context, or the group's first one
+    pt_group *group_ = nullptr;
     FlatScene loaded_{};
     bool have_scene_ = false;
     uint32_t next_sample_ = 0;
@@ -102,6 +105,15 @@ class Renderer {
     {
         if (rc != PT_OK) throw Error(rc, pt_last_error(ctx_));
     }
+    void gcheck(int rc) const
+    {
+        if (rc != PT_OK) throw Error(rc, pt_group_last_error(group_));
+    }
+    // a group's sums live on its members until they are reduced
+    void settle() const
+    {
+        if (group_) gcheck(pt_group_read_accum(group_, nullptr, nullptr));
+    }
 
   public:
     explicit Renderer(int device = 0)
@@ -109,11 +121,23 @@ class Renderer {
         const int rc = pt_create(device, &ctx_);
         if (rc != PT_OK) throw Error(rc, pt_global_error());
     }
-    ~Renderer() { pt_destroy(ctx_); }
+    // One renderer over several devices (a single device makes a group of one).
+    explicit Renderer(const std::vector<int> &devices)
+    {
+        const int rc = pt_group_create(devices.data(), static_cast<int>(devices.size()), &group_);
+        if (rc != PT_OK) throw Error(rc, pt_group_last_error(nullptr));
+        ctx_ = pt_group_context(group_, 0);
+    }
+    ~Renderer()
+    {
+        if (group_) pt_group_destroy(group_);
+        else pt_destroy(ctx_);
+    }
     Renderer(const Renderer &) = delete;
     Renderer &operator=(const Renderer &) = delete;
 
     pt_ctx *context() const { return ctx_; }
+    int devices() const { return group_ ? pt_group_size(group_) : 1; }
 
     // Uploads whatever changed since the last call.  A changed camera, DOF
     // setting, image size or scene clears the accumulated image, the condition
@@ -124,12 +148,13 @@ class Renderer {
         FlatScene f = flatten(scene, width, height);
         bool cleared = false;
         if (!have_scene_ || !f.same_geometry(loaded_)) {
-            check(pt_set_scene(ctx_, f.surfaces.data(), static_cast<int32_t>(f.surfaces.size()),
-                               f.materials.data(), static_cast<int32_t>(f.materials.size()), f.bg));
+            const int32_t n = static_cast<int32_t>(f.surfaces.size()), m = static_cast<int32_t>(f.materials.size());
+            if (group_) gcheck(pt_group_set_scene(group_, f.surfaces.data(), n, f.materials.data(), m, f.bg));
+            else check(pt_set_scene(ctx_, f.surfaces.data(), n, f.materials.data(), m, f.bg));
             cleared = true;
         }
         if (cleared || !f.same_camera(loaded_)) {
-            check(pt_set_camera(ctx_, &f.camera));   // clears
+            set_camera(f.camera);   // clears
             cleared = true;
         }
         loaded_ = std::move(f);
@@ -145,24 +170,36 @@ class Renderer {
         if (!have_scene_) return sync(scene, width, height);
         const pt_camera cam = flatten_camera(scene, width, height);
         if (std::memcmp(&cam, &loaded_.camera, sizeof cam) == 0) return false;
-        check(pt_set_camera(ctx_, &cam));   // clears
+        set_camera(cam);   // clears
         loaded_.camera = cam;
         return true;
     }
 
-    void clear() { check(pt_clear(ctx_)); }
+    void set_camera(const pt_camera &cam)
+    {
+        if (group_) gcheck(pt_group_set_camera(group_, &cam));
+        else check(pt_set_camera(ctx_, &cam));
+    }
+
+    void clear()
+    {
+        if (group_) gcheck(pt_group_clear(group_));
+        else check(pt_clear(ctx_));
+    }
 
     // Adds spp samples per pixel; sample numbers continue across calls so no
     // two passes repeat a random stream.
     void render(uint32_t spp, uint64_t seed = 1, int mode = PT_MODE_MEGAKERNEL | PT_NUM_EXACT)
     {
-        check(pt_render(ctx_, spp, next_sample_, seed, mode));
+        if (group_) gcheck(pt_group_render(group_, spp, next_sample_, seed, mode));
+        else check(pt_render(ctx_, spp, next_sample_, seed, mode));
         next_sample_ += spp;
     }
 
     uint64_t total_samples() const
     {
         uint64_t n = 0;
+        settle();
         check(pt_read_accum(ctx_, nullptr, &n));
         return n;
     }
@@ -171,6 +208,7 @@ class Renderer {
     std::vector<float> read_sums() const
     {
         std::vector<float> sums(static_cast<size_t>(loaded_.camera.width) * loaded_.camera.height * 3);
+        settle();
         check(pt_read_accum(ctx_, sums.data(), nullptr));
         return sums;
     }
@@ -180,6 +218,7 @@ class Renderer {
     const float *map_sums() const
     {
         const float *sums = nullptr;
+        settle();
         check(pt_map_accum(ctx_, &sums, nullptr));
         return sums;
     }
@@ -189,6 +228,7 @@ class Renderer {
     {
         if (sums.size() != static_cast<size_t>(loaded_.camera.width) * loaded_.camera.height * 3)
             throw Error(PT_E_INVALID, "write_sums: size does not match the image");
+        if (group_) throw Error(PT_E_INVALID, "write_sums: a group's image is the sum of its members' shares");
         check(pt_write_accum(ctx_, sums.data(), total_samples));
     }
 
@@ -196,10 +236,12 @@ class Renderer {
     std::vector<uint8_t> tonemap() const
     {
         std::vector<uint8_t> rgb(static_cast<size_t>(loaded_.camera.width) * loaded_.camera.height * 3);
+        settle();
         check(pt_tonemap_rgb8(ctx_, rgb.data()));
         return rgb;
     }
 
+    // Counters of the last render on the context (a group's first member).
     pt_counters counters() const
     {
         pt_counters c{};

@@ -481,7 +481,18 @@ def test_cpp_headless_trace_rays_drop_in(pt, orc, tmp_path):
                           "-batch", "8"], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stderr
     fields = dict(kv.split("=") for kv in res.stdout.split())
-    assert fields["samples_per_pixel"] == "16"
+    assert fields["samples_per_pixel"] == "16" and fields["gpus"] == "1"
+    batched_mean = fields["mean_rgb"]
+    # the same through a group of the box's GPUs (pt_group_*: one RCCL reduce at the end)
+    import torch
+    n = torch.cuda.device_count()
+    res = subprocess.run([exe, "-scene", "orange_plane", "-width", "64", "-height", "40", "-passes", "2",
+                          "-batch", "8", "-gpus", str(n)], capture_output=True, text=True, timeout=180)
+    assert res.returncode == 0, res.stderr
+    line = [l for l in res.stdout.splitlines() if l.startswith("scene=")][-1]     # RCCL may print too
+    fields = dict(kv.split("=") for kv in line.split())
+    assert fields["samples_per_pixel"] == "16" and fields["gpus"] == str(n)
+    assert np.allclose(np.float64(fields["mean_rgb"].split(",")), np.float64(batched_mean.split(",")), rtol=1e-5)
     res = subprocess.run([exe, "-scene", "nope"], capture_output=True, text=True, timeout=60)
     assert res.returncode == 2
 
