@@ -64,6 +64,39 @@ bool extreme_triangle(const pt_surface &s)
     return !(m1 * m2 <= GEOM_DIRECT_EDGE_PRODUCT);      // also when not a number
 }
 
+// The lean record of a triangle (the FAST policy's scan, pt_device.hpp): unit normal n and
+// d0 = n.v0, and the affine maps P -> u, v with o + t d = v0 + u e1 + v e2 at the hit point P.
+// Evaluated in double and rounded once.  A degenerate triangle gets NaNs: never hit.
+void lean_triangle_record(const pt_surface &s, float *ln)
+{
+    const double v0[3] = {s.a[0], s.a[1], s.a[2]};
+    double e1[3], e2[3];
+    for (int k = 0; k < 3; k++) {
+        e1[k] = (double)((float)(s.b[k] - s.a[k]));            // the reference's fp32 edges (surface.hpp:48-49)
+        e2[k] = (double)((float)(s.c[k] - s.a[k]));
+    }
+    auto cross = [](const double *a, const double *b, double *r) {
+        r[0] = a[1] * b[2] - a[2] * b[1]; r[1] = a[2] * b[0] - a[0] * b[2]; r[2] = a[0] * b[1] - a[1] * b[0];
+    };
+    double N[3], ku[3], kv[3];
+    cross(e1, e2, N);
+    const double nn = N[0] * N[0] + N[1] * N[1] + N[2] * N[2], len = std::sqrt(nn);
+    cross(e2, N, ku);
+    cross(N, e1, kv);
+    double d0 = 0, cu = 0, cv = 0;
+    for (int k = 0; k < 3; k++) {
+        ku[k] /= nn; kv[k] /= nn;
+        d0 += N[k] / len * v0[k];
+        cu -= ku[k] * v0[k];
+        cv -= kv[k] * v0[k];
+    }
+    for (int k = 0; k < 3; k++) { ln[k] = (float)(N[k] / len); ln[5 + k] = (float)ku[k]; ln[9 + k] = (float)kv[k]; }
+    ln[4] = (float)d0;
+    ln[8] = (float)cu;
+    ln[13] = (float)cv;
+    ln[14] = (float)(1e-5 / len);      // |determinant(-d, e1, e2)| = |n.d| |N| against EPSILON (surface.hpp:53)
+}
+
 uint32_t host_pcg(uint32_t v)
 {
     uint32_t s = v * 747796405u + 2891336453u;
@@ -86,7 +119,7 @@ struct pt_ctx {
     int n_surfaces = 0, n_tri = 0, n_sph = 0;
     float bg[3] = {0, 0, 0};
     Camera cam{};
-    float *d_geom = nullptr, *d_shade = nullptr;
+    float *d_geom = nullptr, *d_shade = nullptr, *d_lean = nullptr;
 
     // hierarchy over the small triangles (n_bvh == 0: none) and the surfaces left outside it
     int accel = PT_ACCEL_AUTO;
@@ -146,6 +179,9 @@ int fail(pt_ctx *ctx, int code, const char *fmt, ...)
 int use_device(pt_ctx *ctx)
 {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // the runtime's "last error" is per thread and sticky: whatever another library left there
+    // (RCCL probes devices when a communicator is made) must not be taken for a failed launch here
+    (void)hipGetLastError();
     return PT_OK;
 }
 
@@ -338,6 +374,7 @@ SceneView scene_view(const pt_ctx *ctx)
 {
     SceneView v{};
     v.geom = ctx->d_geom;
+    v.lean = ctx->d_lean;
     v.shade = ctx->d_shade;
     v.n_surfaces = ctx->n_surfaces;
     v.n_scan = ctx->n_bvh > 0 ? ctx->n_loose : ctx->n_surfaces;
@@ -731,6 +768,7 @@ void pt_destroy(pt_ctx *ctx)
     for (hipEvent_t ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
     if (ctx->d_geom) (void)hipFree(ctx->d_geom);
     if (ctx->d_shade) (void)hipFree(ctx->d_shade);
+    if (ctx->d_lean) (void)hipFree(ctx->d_lean);
     if (ctx->d_loose) (void)hipFree(ctx->d_loose);
     if (ctx->d_loose_geom) (void)hipFree(ctx->d_loose_geom);
     if (ctx->d_bvh_nodes) (void)hipFree(ctx->d_bvh_nodes);      // the leaves live in the same allocation
@@ -777,6 +815,7 @@ static int set_scene_body(pt_ctx *ctx, const pt_surface *surfaces, int32_t n_sur
 
     std::vector<float> geom((size_t)std::max(n_surfaces, 1) * GEOM_STRIDE, 0.0f);
     std::vector<float> shade((size_t)std::max(n_surfaces, 1) * SHADE_STRIDE, 0.0f);
+    std::vector<float> lean((size_t)std::max(n_surfaces, 1) * LEAN_STRIDE, 0.0f);
     int n_tri = 0, n_sph = 0;
     for (int i = 0; i < n_surfaces; i++) {
         const pt_surface &s = surfaces[i];
@@ -787,8 +826,10 @@ static int set_scene_body(pt_ctx *ctx, const pt_surface *surfaces, int32_t n_sur
             return fail(ctx, PT_E_INVALID, "material %d has unknown type %d", s.material, m.type);
         float *g = &geom[(size_t)i * GEOM_STRIDE];
         float *sh = &shade[(size_t)i * SHADE_STRIDE];
+        float *ln = &lean[(size_t)i * LEAN_STRIDE];
         const int32_t kind = s.kind;
         memcpy(g + 3, &kind, 4);
+        memcpy(ln + 3, &kind, 4);
         if (kind == PT_TRIANGLE) {
             const HostV3 v0{s.a[0], s.a[1], s.a[2]}, v1{s.b[0], s.b[1], s.b[2]}, v2{s.c[0], s.c[1], s.c[2]};
             const HostV3 e1 = hsub(v1, v0), e2 = hsub(v2, v0);          // surface.hpp:48-49
@@ -799,11 +840,14 @@ static int set_scene_body(pt_ctx *ctx, const pt_surface *surfaces, int32_t n_sur
             g[8] = e2.x; g[9] = e2.y; g[10] = e2.z;
             if (extreme_triangle(s)) g[7] = NAN;
             sh[8] = nrm.x; sh[9] = nrm.y; sh[10] = nrm.z;
+            lean_triangle_record(s, ln);
             n_tri++;
         } else if (kind == PT_SPHERE) {
             g[0] = s.a[0]; g[1] = s.a[1]; g[2] = s.a[2];
             g[4] = s.b[0] * s.b[0];                                      // surface.hpp:83
             sh[8] = s.a[0]; sh[9] = s.a[1]; sh[10] = s.a[2];
+            ln[0] = s.a[0]; ln[1] = s.a[1]; ln[2] = s.a[2];
+            ln[4] = g[4];
             n_sph++;
         } else {
             return fail(ctx, PT_E_INVALID, "surface %d has unknown kind %d", i, kind);
@@ -818,15 +862,19 @@ static int set_scene_body(pt_ctx *ctx, const pt_surface *surfaces, int32_t n_sur
     for (int i = n_surfaces - 1, run = 0; i >= 0; i--) {
         run = (i + 1 < n_surfaces && surfaces[i + 1].kind == surfaces[i].kind) ? run + 1 : 1;
         memcpy(&geom[(size_t)i * GEOM_STRIDE + GEOM_RUN], &run, 4);
+        memcpy(&lean[(size_t)i * LEAN_STRIDE + GEOM_RUN], &run, 4);
     }
 
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_geom) (void)hipFree(ctx->d_geom);
     if (ctx->d_shade) (void)hipFree(ctx->d_shade);
-    ctx->d_geom = ctx->d_shade = nullptr;
+    if (ctx->d_lean) (void)hipFree(ctx->d_lean);
+    ctx->d_geom = ctx->d_shade = ctx->d_lean = nullptr;
     ctx->have_scene = false;
     if ((rc = dev_alloc(ctx, &ctx->d_geom, geom.size()))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->d_shade, shade.size()))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_lean, lean.size()))) return rc;
+    HIP_TRY(ctx, hipMemcpy(ctx->d_lean, lean.data(), lean.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->d_geom, geom.data(), geom.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->d_shade, shade.data(), shade.size() * sizeof(float), hipMemcpyHostToDevice));
     ctx->n_surfaces = n_surfaces;

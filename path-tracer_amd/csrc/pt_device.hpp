@@ -681,6 +681,117 @@ PT_DEV Hit closest_intersection(cfloat_p geom, int n_surfaces, V3 o, V3 d,
     return scan_finish<FAST, NEED_DIST>(st, d);
 }
 
+// ---- the FAST policy's own scan ------------------------------------------------
+//
+// PT_NUM_FAST promises images that agree statistically, not the reference's decisions, so
+// its linear scan does not evaluate the reference's four determinants at all: a triangle is
+// a plane (unit normal n, offset d0 = n.v0) and two affine functions of the hit point that
+// give its barycentric coordinates,
+//     t = (d0 - n.o) / (n.d)    P = o + t d    u = Ku.P + cu    v = Kv.P + cv
+// with Ku = (e2 x N) / |N|^2, Kv = (N x e1) / |N|^2, N = e1 x e2 (so that
+// o + t d = v0 + u e1 + v e2, src/surface.hpp:47-66), all fused multiply-adds: 17 arithmetic
+// instructions against 29 for the fused determinants.  The reference's acceptance tests
+// (src/surface.hpp:53-66) become one signed margin, positive inside:
+//     min(min(u, v) + eps, 1 - (u + v), t - eps, |n.d| - eps / |N|)
+// (u < 1 follows from the other two), one comparison.  A NaN anywhere (a degenerate
+// triangle's record, a non-finite ray) fails that comparison: no hit.
+//
+// Lean record, 16 floats per surface, scene order, read with wave-uniform indices:
+//  triangle: [0..2] n  [3] kind  [4] d0  [5..7] Ku  [8] cu  [9..11] Kv  [12] run  [13] cv  [14] eps / |N|
+//  sphere:   [0..2] position  [3] kind  [4] radius2                       [12] run
+constexpr int LEAN_STRIDE = 16;
+
+struct LeanRec { f32x4 q0, q1, q2, q3; int kind; };
+
+PT_DEV LeanRec lean_load(cfloat_p g)
+{
+    typedef const __attribute__((address_space(4))) f32x4 *cf32x4_p;
+    typedef const __attribute__((address_space(4))) i32x4 *ci32x4_p;
+    const cf32x4_p p = (cf32x4_p)g;
+    // the kind is read as an integer lane of an integer vector (see geom_load)
+    const i32x4 first = ((ci32x4_p)g)[0];
+    LeanRec r;
+    r.kind = first.w;
+    r.q0 = __builtin_bit_cast(f32x4, first);
+    r.q1 = p[1]; r.q2 = p[2]; r.q3 = p[3];
+    return r;
+}
+
+// Best hit so far of a lean scan: code = 4 * surface index + mode (0 triangle: dist = t |d|;
+// 1 sphere: dist = t), or negative; dist = +infinity before the first hit.
+struct LeanBest { int code; float dist; };
+
+template <bool WAVE_SKIP>
+PT_DEV void lean_triangle(LeanBest &best, int i, const LeanRec &r, V3 o, V3 d, float len_d)
+{
+    const float nx = r.q0.x, ny = r.q0.y, nz = r.q0.z;
+    const float den = __builtin_fmaf(nz, d.z, __builtin_fmaf(ny, d.y, nx * d.x));
+    const float num = __builtin_fmaf(-nz, o.z, __builtin_fmaf(-ny, o.y, __builtin_fmaf(-nx, o.x, r.q1.x)));
+    const float t = num * __builtin_amdgcn_rcpf(den);
+    const float px = __builtin_fmaf(t, d.x, o.x), py = __builtin_fmaf(t, d.y, o.y), pz = __builtin_fmaf(t, d.z, o.z);
+    const float u = __builtin_fmaf(r.q1.w, pz, __builtin_fmaf(r.q1.z, py, __builtin_fmaf(r.q1.y, px, r.q2.x)));
+    const float v = __builtin_fmaf(r.q2.w, pz, __builtin_fmaf(r.q2.z, py, __builtin_fmaf(r.q2.y, px, r.q3.y)));
+    const float inside = __builtin_fminf(__builtin_fminf(u, v) + EPS_F, 1.0f - (u + v));
+    const float ahead = __builtin_fminf(t - EPS_F, __builtin_fabsf(den) - r.q3.z);
+    const float margin = __builtin_fminf(inside, ahead);          // min3 + min
+    const float dist = t * len_d;
+    if (margin > 0.0f && dist < best.dist) best = {4 * i, dist};
+}
+
+template <bool WAVE_SKIP>
+PT_DEV void lean_sphere(LeanBest &best, int i, const LeanRec &r, V3 o, V3 d)
+{
+    const float lx = r.q0.x - o.x, ly = r.q0.y - o.y, lz = r.q0.z - o.z;
+    const float tca = __builtin_fmaf(lz, d.z, __builtin_fmaf(ly, d.y, lx * d.x));
+    const float ll = __builtin_fmaf(lz, lz, __builtin_fmaf(ly, ly, lx * lx));
+    const float arg = r.q1.x - __builtin_fmaf(-tca, tca, ll);    // radius2 - d2, src/surface.hpp:97-101
+    if constexpr (WAVE_SKIP) {
+        // no lane of the wave gets past the reference's first two tests: no square root
+        if (!__any(tca >= 0.0f && arg >= 0.0f)) return;
+    }
+    const float thc = __builtin_amdgcn_sqrtf(arg);
+    const float t1 = tca - thc, t2 = tca + thc;
+    const float t = t1 > EPS_F ? t1 : t2;                        // src/surface.hpp:103-109
+    // tca >= 0, d2 <= radius2, t > eps: one margin, positive when all hold (a NaN root, when
+    // d2 > radius2, drops out of the minimum, but arg is negative then; tca = 0 and d2 = radius2
+    // exactly, accepted by the reference, are not: sets of measure zero)
+    const float margin = __builtin_fminf(__builtin_fminf(tca, arg), t - EPS_F);
+    if (margin > 0.0f && t < best.dist) best = {4 * i + 1, t};
+}
+
+// closest_intersection (src/main.cpp:56-67) for the FAST policy over lean records.
+template <bool WAVE_SKIP>
+PT_DEV Hit closest_intersection_lean(cfloat_p lean, int n_surfaces, V3 o, V3 d)
+{
+    LeanBest best = {-4, __builtin_inff()};
+    const float len2 = __builtin_fmaf(d.z, d.z, __builtin_fmaf(d.y, d.y, d.x * d.x));
+    const float len_d = __builtin_amdgcn_sqrtf(len2);
+    if constexpr (!WAVE_SKIP) {
+        for (int i = 0; i < n_surfaces; i++) {
+            const LeanRec r = lean_load(lean + (size_t)i * LEAN_STRIDE);
+            if (r.kind == GEOM_TRIANGLE) lean_triangle<false>(best, i, r, o, d, len_d);   // wave-uniform
+            else lean_sphere<false>(best, i, r, o, d);
+        }
+    } else {
+        // many surfaces: run by run, one loop per kind (see closest_intersection)
+        for (int i = 0; i < n_surfaces;) {
+            cfloat_p head = lean + (size_t)i * LEAN_STRIDE;
+            const int end = i + __builtin_bit_cast(int, head[GEOM_RUN]);
+            if (__builtin_bit_cast(int, head[3]) == GEOM_TRIANGLE) {
+                for (; i < end; i++) lean_triangle<true>(best, i, lean_load(lean + (size_t)i * LEAN_STRIDE), o, d, len_d);
+            } else {
+                for (; i < end; i++) lean_sphere<true>(best, i, lean_load(lean + (size_t)i * LEAN_STRIDE), o, d);
+            }
+        }
+    }
+    Hit h;
+    h.idx = best.code >> 2;
+    h.dist = h.idx < 0 ? 0.0f : best.dist;
+    h.t = (best.code & 3) == 0 ? best.dist * __builtin_amdgcn_rcpf(len_d) : best.dist;
+    if (h.idx < 0) h.t = 0.0f;
+    return h;
+}
+
 // ---------------------------------------------------------------- materials
 
 // sample_diffuse, src/material.hpp:13-27: a uniform direction on the sphere,

@@ -23,6 +23,7 @@ constexpr int MAX_LDS_SURFACES = 64 * 1024 / (12 * 4);   // shading records kept
 // small triangles are searched through the hierarchy.
 struct SceneView {
     const float *geom;        // every surface's geometry record, scene order, read through the scalar cache
+    const float *lean;        // every surface's lean record (the FAST policy's scan), same order
     const float *shade;       // every surface's shading record
     int n_scan;               // surfaces scanned linearly
     int n_surfaces;           // surfaces in the scene
@@ -46,7 +47,8 @@ template <bool FAST, bool NEED_DIST, int KIND, bool WAVE_SKIP = false>
 PT_DEV Hit closest_hit(const SceneView &sc, V3 o, V3 d, float *lds, unsigned long long *redo_count = nullptr)
 {
     if constexpr (KIND != SCENE_BVH) {
-        return closest_intersection<FAST, NEED_DIST, WAVE_SKIP>(as_constant(sc.geom), sc.n_scan, o, d, redo_count);
+        if constexpr (FAST) return closest_intersection_lean<WAVE_SKIP>(as_constant(sc.lean), sc.n_scan, o, d);
+        else return closest_intersection<FAST, NEED_DIST, WAVE_SKIP>(as_constant(sc.geom), sc.n_scan, o, d, redo_count);
     } else {
         Hit h = closest_intersection<FAST, true>(as_constant(sc.loose_geom), sc.n_scan, o, d, redo_count);
         if (h.idx >= 0) h.idx = sc.loose[h.idx];

@@ -7,36 +7,43 @@
 #include "pt_scene_io.hpp"
 #include "pt_scenes.hpp"
 
+namespace {
+thread_local std::string g_host_error;
+}  // namespace
+
 extern "C" {
 
 // Flattens scene `name` (Scenes::by_name) for a width x height image (focal
 // length = height pixels).  surfaces/materials hold `capacity` entries.
 // Returns 0, -1 for an unknown name, -2 if capacity is too small; *n_surfaces
 // is set to the scene's size in both of the last two cases, so a caller can
-// size its arrays with a first call of capacity 0.
+// size its arrays with a first call of capacity 0; -3 if building the scene
+// failed (out of memory for a huge synthetic scene; pt_host_last_error says).
 int pt_host_builtin_scene(const char *name, int width, int height, pt_surface *surfaces,
                           pt_material *materials, int32_t capacity, int32_t *n_surfaces,
                           float bg[3], pt_camera *camera)
 {
     set_screen_size(width, height);
-    std::optional<Scene> scene;
-    if (!Scenes::by_name(name, scene)) return -1;
-    const pt::FlatScene flat = pt::flatten(*scene, width, height);
-    *n_surfaces = static_cast<int32_t>(flat.surfaces.size());
-    if (*n_surfaces > capacity) return -2;
-    for (size_t i = 0; i < flat.surfaces.size(); i++) {
-        surfaces[i] = flat.surfaces[i];
-        materials[i] = flat.materials[i];
+    try {
+        std::optional<Scene> scene;
+        if (!Scenes::by_name(name, scene)) return -1;
+        const pt::FlatScene flat = pt::flatten(*scene, width, height);
+        *n_surfaces = static_cast<int32_t>(flat.surfaces.size());
+        if (*n_surfaces > capacity) return -2;
+        for (size_t i = 0; i < flat.surfaces.size(); i++) {
+            surfaces[i] = flat.surfaces[i];
+            materials[i] = flat.materials[i];
+        }
+        std::memcpy(bg, flat.bg, sizeof flat.bg);
+        *camera = flat.camera;
+        return 0;
+    } catch (const std::exception &e) {     // no exception may unwind through a C caller
+        g_host_error = e.what();
+        return -3;
     }
-    *n_surfaces = static_cast<int32_t>(flat.surfaces.size());
-    std::memcpy(bg, flat.bg, sizeof flat.bg);
-    *camera = flat.camera;
-    return 0;
 }
 
 namespace {
-thread_local std::string g_host_error;
-
 int emit(const Scene &scene, int width, int height, pt_surface *surfaces, pt_material *materials,
          int32_t capacity, int32_t *n_surfaces, float bg[3], pt_camera *camera)
 {
@@ -81,12 +88,18 @@ int pt_host_load_scene(const char *path, int width, int height, pt_surface *surf
 int pt_host_save_scene(const char *name, int width, int height, const char *path)
 {
     set_screen_size(width, height);
-    std::optional<Scene> scene;
-    if (!Scenes::by_name(name, scene)) return -1;
-    std::ofstream out(path);
-    if (!out) { g_host_error = std::string("cannot write ") + path; return -3; }
-    pt::save_scene(*scene, out);
-    return out.good() ? 0 : -3;
+    try {
+        std::optional<Scene> scene;
+        if (!Scenes::by_name(name, scene)) return -1;
+        std::ofstream out(path);
+        if (!out) { g_host_error = std::string("cannot write ") + path; return -3; }
+        pt::save_scene(*scene, out);
+        if (!out.good()) { g_host_error = std::string("error while writing ") + path; return -3; }
+        return 0;
+    } catch (const std::exception &e) {
+        g_host_error = e.what();
+        return -3;
+    }
 }
 
 // Camera pose -> rotation matrix through class Camera (src/camera.hpp:20-39).

@@ -147,12 +147,17 @@ def builtin_scene(name, width, height):
                                     C.c_int32(0), C.byref(n), _p(bg), _p(cam))
     if rc == -1:
         raise KeyError("unknown scene %r" % name)
+    if rc == -3:
+        host.pt_host_last_error.restype = C.c_char_p
+        raise RuntimeError("pt_host_builtin_scene(%r): %s" % (name, host.pt_host_last_error().decode()))
     surf = np.zeros(max(n.value, 1), dtype=SURFACE)
     mats = np.zeros(max(n.value, 1), dtype=MATERIAL)
     rc = host.pt_host_builtin_scene(name.encode(), int(width), int(height), _p(surf), _p(mats),
                                     C.c_int32(len(surf)), C.byref(n), _p(bg), _p(cam))
     if rc != 0:
-        raise RuntimeError("pt_host_builtin_scene(%r) failed with %d" % (name, rc))
+        host.pt_host_last_error.restype = C.c_char_p
+        raise RuntimeError("pt_host_builtin_scene(%r) failed with %d: %s" % (
+            name, rc, host.pt_host_last_error().decode() if rc == -3 else ""))
     return SceneData(surf[:n.value], mats[:n.value], bg, cam)
 
 

@@ -27,9 +27,16 @@ def partition_samples(total_spp, world, rank, first_sample=0):
 def render_share(renderer, accum, total_spp, world, rank, first_sample=0, seed=1, mode=0):
     """Adds this rank's share of the samples into `accum` (a torch tensor of
     height x width x 3 float32 on the renderer's device).  `renderer` offers
-    render_into(device_ptr, spp, first_sample, seed, mode), as pt_amd.Context does."""
+    render_into(device_ptr, spp, first_sample, seed, mode), as pt_amd.Context does.
+    The launch is put on torch's current stream (renderer.set_stream, when the renderer
+    has one and accum is a device tensor), the stream the reduce that follows runs on:
+    the library does not wait for its kernels, so on any other stream the reduce could
+    read an image still being written."""
     first, count = partition_samples(total_spp, world, rank, first_sample)
     if count > 0:
+        if getattr(accum, "is_cuda", False) and hasattr(renderer, "set_stream"):
+            import torch
+            renderer.set_stream(torch.cuda.current_stream(accum.device).cuda_stream)
         renderer.render_into(accum.data_ptr(), count, first, seed, mode)
     return count
 

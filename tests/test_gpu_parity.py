@@ -271,6 +271,38 @@ def test_converged_image_rmse(ctx, pt, golden, name, numeric):
     assert abs(cnt.segments / cnt.samples - float(g[name + "_segments_per_sample"])) < 0.02
 
 
+@pytest.mark.parametrize("numeric", ["exact", "fast"])
+@pytest.mark.parametrize("name", ["cornell_2", "orange_plane", "cornell", "glass_stress", "heightfield:6",
+                                  "heightfield:40"])
+def test_converged_image_against_the_reference_generator(ctx, pt, golden, name, numeric):
+    """The statistical gate proper: 4096 spp at 64 x 64 against the oracle driven by the
+    reference's own random numbers (libc rand() through random_real, src/main.cpp:42-44, one
+    serial stream per image as trace_rays draws it; tests/golden/make_golden_libc.py).  The HIP
+    path's counter-based generator makes its image statistically independent of that one, so
+    this compares two estimates of the same integral.  Bound: per-channel RMSE <= 1.5 x the
+    RMSE between two independent libc-rand() images of 4096 spp (the noise floor; the expected
+    ratio for an unbiased renderer is 1), and the image mean within 2.5 % per channel.  The
+    height fields go through the hierarchy."""
+    g = golden("render_libc_64_4096spp.npz")
+    key = name.replace(":", "_")
+    mode = pt.NUM_FAST if numeric == "fast" else pt.NUM_EXACT
+    acc, cnt = render(ctx, pt, pt.builtin_scene(name, 64, 64), 4096, seed=77, mode=mode)
+    if name.startswith("heightfield"):
+        assert cnt.accel == pt.ACCEL_BVH
+    mean = acc / 4096
+    ref, ref2 = g[key + "_mean"], g[key + "_mean_other_seeds"]
+    floor = np.sqrt(((ref - ref2) ** 2).mean((0, 1)))
+    rmse = np.sqrt(((mean - ref) ** 2).mean((0, 1)))
+    rmse2 = np.sqrt(((mean - ref2) ** 2).mean((0, 1)))
+    print("%s %s: rmse/floor %s and %s, mean ratio %s" % (
+        name, numeric, (rmse / floor).round(3), (rmse2 / floor).round(3),
+        (mean.mean((0, 1)) / ref.mean((0, 1))).round(4)))
+    assert (np.maximum(rmse, rmse2) <= 1.5 * floor).all()
+    both = 0.5 * (ref.mean((0, 1)) + ref2.mean((0, 1)))
+    assert np.allclose(mean.mean((0, 1)), both, rtol=0.025)
+    assert abs(cnt.segments / cnt.samples - float(g[key + "_segments_per_sample"])) < 0.02
+
+
 def test_render_is_deterministic_and_ranges_add_up(ctx, pt):
     """Bitwise repeatable; disjoint sample ranges sum to the one-range image up to fp32
     addition order (the property the multi-GPU sample partition rests on)."""
