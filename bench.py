@@ -44,8 +44,9 @@ def parse():
     ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per step per GPU")
     ap.add_argument("--numeric", choices=["exact", "fast"], default="exact")
     ap.add_argument("--layout", choices=["megakernel", "wavefront"], default="megakernel")
-    ap.add_argument("--accel", choices=["auto", "none", "bvh"], default="auto",
-                    help="pt_set_accel mode: hierarchy by the library's rule, never, or whenever possible")
+    ap.add_argument("--accel", choices=["auto", "none", "bvh", "tiles"], default="auto",
+                    help="pt_set_accel mode: hierarchy by the library's rule, never, whenever possible, "
+                         "or the linear scan with its records staged through LDS tiles")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-spp", type=int, default=32,
                     help="samples per pixel of the CPU baseline's bounded sample (0 = skip)")
@@ -160,7 +161,8 @@ def main():
            (pt_amd.NUM_FAST if args.numeric == "fast" else pt_amd.NUM_EXACT)
     scene = pt_amd.builtin_scene(args.scene, width, height)
     ctx = pt_amd.Context(device)
-    ctx.set_accel({"auto": pt_amd.ACCEL_AUTO, "none": pt_amd.ACCEL_NONE, "bvh": pt_amd.ACCEL_BVH}[args.accel])
+    ctx.set_accel({"auto": pt_amd.ACCEL_AUTO, "none": pt_amd.ACCEL_NONE, "bvh": pt_amd.ACCEL_BVH,
+                   "tiles": pt_amd.ACCEL_LDS_TILES}[args.accel])
     ctx.load(scene)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     accum = torch.zeros(height, width, 3, dtype=torch.float32, device="cuda")

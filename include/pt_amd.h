@@ -49,9 +49,11 @@ extern "C" {
 #define PT_ACCEL_NONE 1   /* always the reference's linear scan over every surface */
 #define PT_ACCEL_BVH  2   /* hierarchy whenever the scene has two small triangles or more;
                              PT_E_LIMIT beyond 2^25 of them */
-#define PT_ACCEL_LDS_TILES 3  /* linear scan; pt_primary_hits and pt_intersect_rays stage the records
-                                 through LDS in tiles shared by a workgroup (a layout kept for
-                                 comparison), pt_render scans as with PT_ACCEL_NONE */
+#define PT_ACCEL_LDS_TILES 3  /* linear scan with the records staged through LDS in tiles shared by a
+                                 workgroup (pt_render's megakernel, pt_primary_hits, pt_intersect_rays):
+                                 the layout kept to be measured against PT_ACCEL_NONE's scan through
+                                 the scalar cache, which is faster on every scene measured; the
+                                 wavefront layout scans as with PT_ACCEL_NONE */
 
 /* One Surface, in scene order (Scene::surfaces, src/scene.hpp:18).
  * Triangle (src/surface.hpp:33-35): a,b,c = v0,v1,v2.

@@ -433,7 +433,7 @@ template <bool FAST, int KIND>
 int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample, uint64_t seed, Workspace ws)
 {
     const uint32_t n_pixels = (uint32_t)ctx->cam.width * (uint32_t)ctx->cam.height;
-    const size_t lds_bytes = lds_bytes_for(ctx, KIND);
+    size_t lds_bytes = lds_bytes_for(ctx, KIND);
 
     // scenes with a hierarchy have a megakernel of their own
     void (*kernel)(RenderParams) = nullptr;
@@ -442,6 +442,10 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
         // many spheres or many (then small) triangles: most waves miss most of them (see scan_surface)
         if (ctx->n_sph >= WAVE_SKIP_MIN_SPHERES || ctx->n_tri >= WAVE_SKIP_MIN_TRIANGLES)
             kernel = &k_render_mega<FAST, KIND, true>;
+        if (ctx->accel == PT_ACCEL_LDS_TILES) {     // the scan's records through LDS tiles (its own static LDS)
+            kernel = &k_render_mega_tiled<FAST>;
+            lds_bytes = 0;
+        }
     }
     const double samples = (double)n_pixels * spp;
     // Workgroups per CU (= waves per SIMD) for this launch: one more for every doubling of the

@@ -476,6 +476,53 @@ k_render_mega(RenderParams P)
     atomicAdd(P.stats, n_seg);
 }
 
+// The megakernel with the scan's records staged through LDS tiles shared by the workgroup
+// (PT_ACCEL_LDS_TILES; closest_hit_tiled): the layout to measure against the scan through
+// the scalar cache.  The tiles are loaded by all 256 threads between barriers, so the
+// workgroup iterates in step: a lane that finds the queue empty stays in the loop, idle
+// (its ray is a fixed dummy), until no lane of the workgroup has work left.  Shading
+// records are read from global memory: the tiles take the LDS.
+template <bool FAST>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(96)))
+k_render_mega_tiled(RenderParams P)
+{
+    __shared__ __align__(16) float tiles[2 * SCAN_TILE_FLOATS];
+    const float *shade = P.scene.shade;
+    WorkPool pool = {0, 0, false};
+    ItemState it = {false, 0, 0, 0, 0, 0, 0, 0, v3(0, 0, 0)};
+    bool need_path = true, alive = true;
+    PathState ps = {v3(0, 0, 0), v3(0, 0, 1), v3(1, 1, 1), v3(0, 0, 0), {0, 0}, 0};
+    unsigned long long n_seg = 0;
+
+    for (;;) {
+        const bool want = alive && need_path && it.s == it.s_end;
+        if (__any(want)) {                      // wave-uniform: every lane of the wave enters
+            if (want && it.have) item_close(it, P.slabs);
+            const uint32_t got = pool_take(pool, want, P.queue_head, P.n_items, P.pool_batch);
+            if (want) {
+                if (got == NO_ITEM) alive = false;
+                else item_open(it, got, P.cam.width, P.n_pixels, P.first_sample, P.spp, P.chunk_len, P.seed_mix);
+            }
+        }
+        if (__syncthreads_count(alive) == 0) break;             // workgroup-uniform
+        if (alive && need_path) {
+            path_begin(ps, P.cam, it.pixel_key, it.s, it.px, it.py);
+            need_path = false;
+        }
+        const V3 o = alive ? ps.o : v3(0, 0, 0), d = alive ? ps.d : v3(0, 0, 1);
+        const Hit h = closest_hit_tiled<FAST>(P.scene, o, d, tiles);
+        if (alive) {
+            n_seg++;
+            if (shade_hit<FAST>(ps, P.scene, shade, h)) {
+                it.sum = it.sum + ps.col;           // buffer[u][v] += color, main.cpp:139
+                it.s++;
+                need_path = true;
+            }
+        }
+    }
+    atomicAdd(P.stats, n_seg);
+}
+
 // The megakernel for scenes with a hierarchy.  A traversal takes tens of
 // dependent steps whose number differs from lane to lane, so lanes are
 // decoupled at the granularity of one traversal step: a lane whose traversal

@@ -303,6 +303,31 @@ def test_converged_image_against_the_reference_generator(ctx, pt, golden, name, 
     assert abs(cnt.segments / cnt.samples - float(g[key + "_segments_per_sample"])) < 0.02
 
 
+@pytest.mark.parametrize("numeric", ["exact", "fast"])
+def test_render_through_lds_tiles_equals_the_scalar_cache_scan(ctx, pt, numeric):
+    """PT_ACCEL_LDS_TILES in pt_render: the scan's records staged through LDS tiles shared by the
+    workgroup.  EXACT takes the same decisions as the scan through the scalar cache, so the image
+    is the same bit for bit; FAST scans the tiles with the fused determinants and the scalar
+    cache's records with plane equations, so its images agree statistically."""
+    mode = pt.NUM_FAST if numeric == "fast" else pt.NUM_EXACT
+    try:
+        for name, w, h, spp in (("cornell_2", 96, 64, 8), ("glass_stress", 80, 48, 6), ("heightfield:17", 64, 48, 5)):
+            sc = pt.builtin_scene(name, w, h)             # 8, 85 and 586 surfaces: under one tile, and three
+            ctx.set_accel(pt.ACCEL_NONE)
+            a, ca = render(ctx, pt, sc, spp, seed=6, mode=mode)
+            ctx.set_accel(pt.ACCEL_LDS_TILES)
+            b, cb = render(ctx, pt, sc, spp, seed=6, mode=mode)
+            assert ca.samples == cb.samples
+            if numeric == "exact":
+                assert np.array_equal(a, b), name
+                assert ca.segments == cb.segments
+            else:
+                assert abs(int(ca.segments) - int(cb.segments)) <= 0.01 * ca.segments
+                assert np.isclose(a, b, rtol=2e-3, atol=2e-3).all(axis=2).mean() > 0.95, name
+    finally:
+        ctx.set_accel(pt.ACCEL_AUTO)
+
+
 def test_render_is_deterministic_and_ranges_add_up(ctx, pt):
     """Bitwise repeatable; disjoint sample ranges sum to the one-range image up to fp32
     addition order (the property the multi-GPU sample partition rests on)."""
