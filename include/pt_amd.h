@@ -40,6 +40,9 @@ extern "C" {
 /* pt_render mode bits */
 #define PT_MODE_MEGAKERNEL 0x0   /* one persistent kernel, whole paths in registers */
 #define PT_MODE_WAVEFRONT  0x1   /* queue-per-bounce kernels, path state in HBM */
+#define PT_MODE_COUNT_STEPS 0x100 /* megakernel over a hierarchy: also count the nodes opened and the leaf
+                                    triangles tested (pt_counters.node_steps, leaf_steps); a slower
+                                    instantiation, for measurement */
 #define PT_NUM_EXACT       0x0   /* no FMA contraction, IEEE divide/sqrt: the parity arithmetic */
 #define PT_NUM_FAST        0x10  /* FMA + hardware rcp/rsq/sin/cos */
 
@@ -104,6 +107,8 @@ typedef struct pt_counters {
                                   flops then count what the reference's scan would do, not what ran),
                                   else PT_ACCEL_NONE */
     uint32_t reserved;
+    uint64_t node_steps;       /* PT_MODE_COUNT_STEPS: hierarchy node records opened (two box tests each) */
+    uint64_t leaf_steps;       /* PT_MODE_COUNT_STEPS: hierarchy leaf triangles tested */
 } pt_counters;
 
 typedef struct pt_ctx pt_ctx;

@@ -30,6 +30,7 @@ using namespace ptd;
 // device and everything below goes through that pointer.
 constexpr size_t STATIC_SCRATCH_BYTES = PT_STATIC_SCRATCH_BYTES;
 constexpr size_t STATIC_HEADER_BYTES = 256;
+constexpr size_t QUEUE_BYTES = 64;          // the work queue's head and the launch's counters (RenderParams::stats)
 static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
 
 namespace {
@@ -62,39 +63,6 @@ bool extreme_triangle(const pt_surface &s)
         m2 = std::max(m2, std::fabs(s.c[k] - s.a[k]));
     }
     return !(m1 * m2 <= GEOM_DIRECT_EDGE_PRODUCT);      // also when not a number
-}
-
-// The lean record of a triangle (the FAST policy's scan, pt_device.hpp): unit normal n and
-// d0 = n.v0, and the affine maps P -> u, v with o + t d = v0 + u e1 + v e2 at the hit point P.
-// Evaluated in double and rounded once.  A degenerate triangle gets NaNs: never hit.
-void lean_triangle_record(const pt_surface &s, float *ln)
-{
-    const double v0[3] = {s.a[0], s.a[1], s.a[2]};
-    double e1[3], e2[3];
-    for (int k = 0; k < 3; k++) {
-        e1[k] = (double)((float)(s.b[k] - s.a[k]));            // the reference's fp32 edges (surface.hpp:48-49)
-        e2[k] = (double)((float)(s.c[k] - s.a[k]));
-    }
-    auto cross = [](const double *a, const double *b, double *r) {
-        r[0] = a[1] * b[2] - a[2] * b[1]; r[1] = a[2] * b[0] - a[0] * b[2]; r[2] = a[0] * b[1] - a[1] * b[0];
-    };
-    double N[3], ku[3], kv[3];
-    cross(e1, e2, N);
-    const double nn = N[0] * N[0] + N[1] * N[1] + N[2] * N[2], len = std::sqrt(nn);
-    cross(e2, N, ku);
-    cross(N, e1, kv);
-    double d0 = 0, cu = 0, cv = 0;
-    for (int k = 0; k < 3; k++) {
-        ku[k] /= nn; kv[k] /= nn;
-        d0 += N[k] / len * v0[k];
-        cu -= ku[k] * v0[k];
-        cv -= kv[k] * v0[k];
-    }
-    for (int k = 0; k < 3; k++) { ln[k] = (float)(N[k] / len); ln[5 + k] = (float)ku[k]; ln[9 + k] = (float)kv[k]; }
-    ln[4] = (float)d0;
-    ln[8] = (float)cu;
-    ln[13] = (float)cv;
-    ln[14] = (float)(1e-5 / len);      // |determinant(-d, e1, e2)| = |n.d| |N| against EPSILON (surface.hpp:53)
 }
 
 uint32_t host_pcg(uint32_t v)
@@ -140,7 +108,8 @@ struct pt_ctx {
 
     float *d_slabs = nullptr;        // partial sums of the work items
     size_t slab_floats = 0;
-    uint32_t *d_queue = nullptr;     // [0] work counter; [2..3], [4..5]: 64-bit segment and redo counters
+    uint32_t *d_queue = nullptr;     // [0] work counter; 64-bit counters: [2..3] segments, [4..5] redone,
+                                     // [8..9] hierarchy nodes opened, [10..11] hierarchy leaves tested
     const uint32_t *last_queue = nullptr;   // the queue words the last render counted in (d_queue or the static scratch)
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 
@@ -356,10 +325,22 @@ int build_hierarchy(pt_ctx *ctx, const pt_surface *surfaces, int n_surfaces)
     hipLaunchKernelGGL(k_bvh_hierarchy, dim3(blocks), dim3(256), 0, ctx->stream, d_sorted.p, n, d_children.p,
                        d_parent_node.p, d_parent_leaf.p);
     HIP_TRY(ctx, hipGetLastError());
+    // boxes bottom-up, one launch per level (k_bvh_refit_pass); the root's flag is looked at after
+    // every few launches.  A tree over distinct 64-bit keys is at most 64 levels deep.
     HIP_TRY(ctx, hipMemsetAsync(d_arrivals.p, 0, (size_t)n * sizeof(unsigned int), ctx->stream));
-    hipLaunchKernelGGL(k_bvh_refit, dim3(blocks), dim3(256), 0, ctx->stream, d_sorted.p, n, d_children.p,
-                       d_parent_node.p, d_parent_leaf.p, d_bmin.p, d_bmax.p, d_arrivals.p, ctx->d_bvh_nodes);
-    HIP_TRY(ctx, hipGetLastError());
+    {
+        int root_done = n < 2 ? 1 : 0;
+        for (int pass = 1; !root_done; pass++) {
+            if (pass > 2 * BVH_STACK + 2) return fail(ctx, PT_E_HIP, "hierarchy boxes did not reach the root");
+            hipLaunchKernelGGL(k_bvh_refit_pass, dim3(blocks), dim3(256), 0, ctx->stream, d_sorted.p, n, d_children.p,
+                               d_bmin.p, d_bmax.p, pass, reinterpret_cast<int *>(d_arrivals.p), ctx->d_bvh_nodes);
+            HIP_TRY(ctx, hipGetLastError());
+            if (pass % 8 == 0 || pass >= 24) {
+                HIP_TRY(ctx, hipMemcpyAsync(&root_done, d_arrivals.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            }
+        }
+    }
     hipLaunchKernelGGL(k_bvh_leaves, dim3(blocks), dim3(256), 0, ctx->stream, d_sorted.p, n, ctx->d_geom, d_inside.p,
                        ctx->d_bvh_leaves);
     HIP_TRY(ctx, hipGetLastError());
@@ -430,7 +411,8 @@ struct Workspace {
 };
 
 template <bool FAST, int KIND>
-int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample, uint64_t seed, Workspace ws)
+int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample, uint64_t seed, Workspace ws,
+                  bool count_steps)
 {
     const uint32_t n_pixels = (uint32_t)ctx->cam.width * (uint32_t)ctx->cam.height;
     size_t lds_bytes = lds_bytes_for(ctx, KIND);
@@ -458,6 +440,7 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
     if constexpr (KIND == SCENE_BVH) {
         kernel = &k_render_mega_bvh<FAST>;
         if (blocks_wanted >= 8) kernel = &k_render_mega_bvh<FAST, 7>;       // from 2e7 samples on
+        if (count_steps) kernel = &k_render_mega_bvh<FAST, 6, true>;
     }
     int blocks_per_cu = 0;
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, BLOCK, lds_bytes));
@@ -530,7 +513,7 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
     P.stats = reinterpret_cast<unsigned long long *>(ws.queue + 2);
     ctx->last_queue = ws.queue;
 
-    HIP_TRY(ctx, hipMemsetAsync(ws.queue, 0, 32, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ws.queue, 0, QUEUE_BYTES, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), lds_bytes, ctx->stream, P);
     HIP_TRY(ctx, hipGetLastError());
@@ -612,7 +595,7 @@ int launch_wavefront(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sam
     std::vector<uint32_t> counts(WF_COUNT_WORDS);
 
     ctx->last_queue = ctx->d_queue;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 32, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, QUEUE_BYTES, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     uint64_t segments = 0;
     uint32_t launches = 0;
@@ -706,7 +689,8 @@ int render_dispatch_body(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first
     if (spp == 0) return fail(ctx, PT_E_INVALID, "spp must be positive");
     if ((uint64_t)first_sample + spp > 0xFFFFFFFFull)
         return fail(ctx, PT_E_LIMIT, "sample numbers must fit in 32 bits");
-    if (mode & ~(PT_MODE_WAVEFRONT | PT_NUM_FAST)) return fail(ctx, PT_E_INVALID, "unknown mode bits 0x%x", mode);
+    if (mode & ~(PT_MODE_WAVEFRONT | PT_NUM_FAST | PT_MODE_COUNT_STEPS))
+        return fail(ctx, PT_E_INVALID, "unknown mode bits 0x%x", mode);
     const bool fast = (mode & PT_NUM_FAST) != 0;
     if (mode & PT_MODE_WAVEFRONT) {
         if (ws.fixed) return fail(ctx, PT_E_INVALID, "the wavefront layout allocates its path state: megakernel only");
@@ -715,7 +699,7 @@ int render_dispatch_body(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first
         });
     }
     return with_variant(fast, scene_kind(ctx), [&]<bool FAST, int KIND>() {
-        return launch_render<FAST, KIND>(ctx, accum, spp, first_sample, seed, ws);
+        return launch_render<FAST, KIND>(ctx, accum, spp, first_sample, seed, ws, (mode & PT_MODE_COUNT_STEPS) != 0);
     });
 }
 
@@ -752,7 +736,7 @@ int pt_create(int device, pt_ctx **out)
             if (e == hipSuccess) g_scratch_ptr[device] = static_cast<unsigned char *>(p);
         }
     }
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_queue, 32);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_queue, QUEUE_BYTES);
     for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipEventCreate(&ctx->ev[i]);
     if (e != hipSuccess) {
         int rc = fail(nullptr, PT_E_HIP, "pt_create on device %d: %s", device, hipGetErrorString(e));
@@ -819,7 +803,6 @@ static int set_scene_body(pt_ctx *ctx, const pt_surface *surfaces, int32_t n_sur
 
     std::vector<float> geom((size_t)std::max(n_surfaces, 1) * GEOM_STRIDE, 0.0f);
     std::vector<float> shade((size_t)std::max(n_surfaces, 1) * SHADE_STRIDE, 0.0f);
-    std::vector<float> lean((size_t)std::max(n_surfaces, 1) * LEAN_STRIDE, 0.0f);
     int n_tri = 0, n_sph = 0;
     for (int i = 0; i < n_surfaces; i++) {
         const pt_surface &s = surfaces[i];
@@ -830,10 +813,8 @@ static int set_scene_body(pt_ctx *ctx, const pt_surface *surfaces, int32_t n_sur
             return fail(ctx, PT_E_INVALID, "material %d has unknown type %d", s.material, m.type);
         float *g = &geom[(size_t)i * GEOM_STRIDE];
         float *sh = &shade[(size_t)i * SHADE_STRIDE];
-        float *ln = &lean[(size_t)i * LEAN_STRIDE];
         const int32_t kind = s.kind;
         memcpy(g + 3, &kind, 4);
-        memcpy(ln + 3, &kind, 4);
         if (kind == PT_TRIANGLE) {
             const HostV3 v0{s.a[0], s.a[1], s.a[2]}, v1{s.b[0], s.b[1], s.b[2]}, v2{s.c[0], s.c[1], s.c[2]};
             const HostV3 e1 = hsub(v1, v0), e2 = hsub(v2, v0);          // surface.hpp:48-49
@@ -844,14 +825,11 @@ static int set_scene_body(pt_ctx *ctx, const pt_surface *surfaces, int32_t n_sur
             g[8] = e2.x; g[9] = e2.y; g[10] = e2.z;
             if (extreme_triangle(s)) g[7] = NAN;
             sh[8] = nrm.x; sh[9] = nrm.y; sh[10] = nrm.z;
-            lean_triangle_record(s, ln);
             n_tri++;
         } else if (kind == PT_SPHERE) {
             g[0] = s.a[0]; g[1] = s.a[1]; g[2] = s.a[2];
             g[4] = s.b[0] * s.b[0];                                      // surface.hpp:83
             sh[8] = s.a[0]; sh[9] = s.a[1]; sh[10] = s.a[2];
-            ln[0] = s.a[0]; ln[1] = s.a[1]; ln[2] = s.a[2];
-            ln[4] = g[4];
             n_sph++;
         } else {
             return fail(ctx, PT_E_INVALID, "surface %d has unknown kind %d", i, kind);
@@ -866,7 +844,6 @@ static int set_scene_body(pt_ctx *ctx, const pt_surface *surfaces, int32_t n_sur
     for (int i = n_surfaces - 1, run = 0; i >= 0; i--) {
         run = (i + 1 < n_surfaces && surfaces[i + 1].kind == surfaces[i].kind) ? run + 1 : 1;
         memcpy(&geom[(size_t)i * GEOM_STRIDE + GEOM_RUN], &run, 4);
-        memcpy(&lean[(size_t)i * LEAN_STRIDE + GEOM_RUN], &run, 4);
     }
 
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -877,9 +854,14 @@ static int set_scene_body(pt_ctx *ctx, const pt_surface *surfaces, int32_t n_sur
     ctx->have_scene = false;
     if ((rc = dev_alloc(ctx, &ctx->d_geom, geom.size()))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->d_shade, shade.size()))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->d_lean, lean.size()))) return rc;
-    HIP_TRY(ctx, hipMemcpy(ctx->d_lean, lean.data(), lean.size() * sizeof(float), hipMemcpyHostToDevice));
+    if ((rc = dev_alloc(ctx, &ctx->d_lean, (size_t)std::max(n_surfaces, 1) * LEAN_STRIDE))) return rc;
     HIP_TRY(ctx, hipMemcpy(ctx->d_geom, geom.data(), geom.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (n_surfaces > 0) {
+        // the FAST policy's records are derived from the geometry records on the device
+        hipLaunchKernelGGL(k_lean_records, dim3(blocks_for(n_surfaces)), dim3(BLOCK), 0, ctx->stream, ctx->d_geom,
+                           n_surfaces, ctx->d_lean);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     HIP_TRY(ctx, hipMemcpy(ctx->d_shade, shade.data(), shade.size() * sizeof(float), hipMemcpyHostToDevice));
     ctx->n_surfaces = n_surfaces;
     ctx->n_tri = n_tri;
@@ -1295,11 +1277,13 @@ int pt_get_counters(pt_ctx *ctx, pt_counters *out)
         float ms_kernel = 0, ms_total = 0;
         HIP_TRY(ctx, hipEventElapsedTime(&ms_kernel, ctx->ev[0], ctx->ev[1]));
         HIP_TRY(ctx, hipEventElapsedTime(&ms_total, ctx->ev[0], ctx->ev[2]));
-        unsigned long long st[2] = {0, 0};
-        HIP_TRY(ctx, hipMemcpy(st, ctx->last_queue + 2, 16, hipMemcpyDeviceToHost));
+        unsigned long long st[5] = {0, 0, 0, 0, 0};
+        HIP_TRY(ctx, hipMemcpy(st, ctx->last_queue + 2, sizeof st, hipMemcpyDeviceToHost));
         const unsigned long long seg = st[0];
         ctx->last.segments = seg;
         ctx->last.redone = st[1];
+        ctx->last.node_steps = st[3];
+        ctx->last.leaf_steps = st[4];
         ctx->last.tests = seg * (uint64_t)ctx->n_surfaces;
         ctx->last.kernel_ms = ms_kernel;
         ctx->last.total_ms = ms_total;

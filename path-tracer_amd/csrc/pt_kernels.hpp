@@ -76,7 +76,8 @@ struct RenderParams {
     float *slabs;             // n_items * 3 partial sums, slab of chunk k at k * n_pixels * 3
     uint32_t pool_batch;      // work items a wave takes from the queue per atomic (POOL_BATCH_MIN..MAX)
     uint32_t *queue_head;     // zeroed before the launch
-    unsigned long long *stats;  // [0] += segments, [1] += segments re-evaluated directly
+    unsigned long long *stats;  // [0] += segments, [1] += segments re-evaluated directly, [3] += hierarchy nodes
+                                // opened, [4] += hierarchy leaves tested (counting instantiations only)
 };
 
 // ---------------------------------------------------------------- parity kernels
@@ -258,6 +259,47 @@ k_rng_uniform(uint32_t seed_mix, const uint32_t *pixel, const uint32_t *sample,
     if (i >= n) return;
     const Rng r = rng_path(rng_pixel(seed_mix, pixel[i]), sample[i]);
     out[i] = rng_at(r, draw[i]);
+}
+
+// The lean records of the FAST policy's scan (pt_device.hpp), one thread per surface, from
+// the geometry records: a triangle's unit normal n and d0 = n.v0, and the affine maps
+// P -> u, v with o + t d = v0 + u e1 + v e2 at the hit point P, evaluated in double and
+// rounded once.  A degenerate triangle gets NaNs: never hit.
+__global__ void __launch_bounds__(BLOCK)
+k_lean_records(const float *geom, int n, float *lean)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float *g = geom + (size_t)i * GEOM_STRIDE;
+    float *ln = lean + (size_t)i * LEAN_STRIDE;
+    float out[LEAN_STRIDE];
+    for (int k = 0; k < LEAN_STRIDE; k++) out[k] = 0.0f;
+    out[3] = g[3];                      // kind
+    out[GEOM_RUN] = g[GEOM_RUN];
+    if (__float_as_int(g[3]) == GEOM_TRIANGLE) {
+        const double v0[3] = {g[0], g[1], g[2]}, e1[3] = {g[4], g[5], g[6]}, e2[3] = {g[8], g[9], g[10]};
+        const double N[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+        const double nn = N[0] * N[0] + N[1] * N[1] + N[2] * N[2], len = sqrt(nn);
+        const double ku[3] = {(e2[1] * N[2] - e2[2] * N[1]) / nn, (e2[2] * N[0] - e2[0] * N[2]) / nn, (e2[0] * N[1] - e2[1] * N[0]) / nn};
+        const double kv[3] = {(N[1] * e1[2] - N[2] * e1[1]) / nn, (N[2] * e1[0] - N[0] * e1[2]) / nn, (N[0] * e1[1] - N[1] * e1[0]) / nn};
+        double d0 = 0, cu = 0, cv = 0;
+        for (int k = 0; k < 3; k++) {
+            d0 += N[k] / len * v0[k];
+            cu -= ku[k] * v0[k];
+            cv -= kv[k] * v0[k];
+            out[k] = (float)(N[k] / len);
+            out[5 + k] = (float)ku[k];
+            out[9 + k] = (float)kv[k];
+        }
+        out[4] = (float)d0;
+        out[8] = (float)cu;
+        out[13] = (float)cv;
+        out[14] = (float)(1e-5 / len);  // |determinant(-d, e1, e2)| = |n.d| |N| against EPSILON (surface.hpp:53)
+    } else {
+        out[0] = g[0]; out[1] = g[1]; out[2] = g[2];
+        out[4] = g[4];
+    }
+    for (int k = 0; k < LEAN_STRIDE; k++) ln[k] = out[k];
 }
 
 // ---------------------------------------------------------------- one path segment
@@ -538,7 +580,9 @@ k_render_mega_tiled(RenderParams P)
 // 72 VGPRs, keeps eight loop-invariant values in scratch memory: 3.4 % faster on a
 // launch large enough to fill seven waves per SIMD, 4 % slower on one that is not;
 // the host picks by launch size.)
-template <bool FAST, int WAVES = 6>
+// COUNT: also counts the node records opened and the leaf triangles tested (stats[3], stats[4]):
+// an instantiation of its own (PT_MODE_COUNT_STEPS), the two counters cost registers.
+template <bool FAST, int WAVES = 6, bool COUNT = false>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 k_render_mega_bvh(RenderParams P)
 {
@@ -556,6 +600,7 @@ k_render_mega_bvh(RenderParams P)
     bool traversing = false;        // false: waiting to shade / start a segment
     bool have_hit = false;          // a finished segment waits to be shaded
     unsigned long long n_seg = 0;
+    uint32_t n_nodes = 0, n_leaves = 0;
 
     for (;;) {
         const int n_alive = __popcll(__ballot(alive));
@@ -603,6 +648,9 @@ k_render_mega_bvh(RenderParams P)
         bvh_fetch_records(P.scene.bvh.nodes, traversing ? bvh_record_of(P.scene.bvh, cur.node) : 0u, lds_wave,
                           q0, q1, q2, q3);
         if (traversing) {
+            if constexpr (COUNT) {
+                if (!cur.direct) { if (cur.node >= 0) n_nodes++; else n_leaves++; }
+            }
             // (a ray that needs the reference's own scan skips the traversal)
             if (cur.direct || !bvh_advance<FAST>(cur, P.scene.bvh, q0, q1, q2, q3, ps.o, ps.d, best, stack, 1)) {
                 traversing = false;
@@ -611,6 +659,10 @@ k_render_mega_bvh(RenderParams P)
         }
     }
     atomicAdd(P.stats, n_seg);
+    if constexpr (COUNT) {
+        atomicAdd(P.stats + 3, (unsigned long long)n_nodes);
+        atomicAdd(P.stats + 4, (unsigned long long)n_leaves);
+    }
 }
 
 // accum[p] += slab_0[p] + slab_1[p] + ... in chunk order (n = n_pixels * 3 floats per slab)

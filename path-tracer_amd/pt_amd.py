@@ -23,6 +23,7 @@ CAMERA = np.dtype([("pos", "<f4", 3), ("rot", "<f4", 9), ("focal", "<f4"),
 DIFFUSE, MIRROR, GLASS = 0, 1, 2
 TRIANGLE, SPHERE = 0, 1
 MODE_MEGAKERNEL, MODE_WAVEFRONT = 0x0, 0x1
+MODE_COUNT_STEPS = 0x100
 NUM_EXACT, NUM_FAST = 0x0, 0x10
 MAX_DEPTH = 1024
 ACCEL_AUTO, ACCEL_NONE, ACCEL_BVH, ACCEL_LDS_TILES = 0, 1, 2, 3
@@ -50,7 +51,8 @@ class Counters(C.Structure):
                 ("redone", C.c_uint64),
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("flops", C.c_double),
                 ("vgprs", C.c_uint32), ("grid_blocks", C.c_uint32),
-                ("accel", C.c_uint32), ("reserved", C.c_uint32)]
+                ("accel", C.c_uint32), ("reserved", C.c_uint32),
+                ("node_steps", C.c_uint64), ("leaf_steps", C.c_uint64)]
 
 
 class PtError(RuntimeError):

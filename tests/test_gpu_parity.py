@@ -328,6 +328,20 @@ def test_render_through_lds_tiles_equals_the_scalar_cache_scan(ctx, pt, numeric)
         ctx.set_accel(pt.ACCEL_AUTO)
 
 
+def test_hierarchy_step_counters(ctx, pt):
+    """PT_MODE_COUNT_STEPS: the same image from the counting instantiation of the hierarchy
+    kernel, with the node records opened and the leaf triangles tested per segment."""
+    sc = pt.builtin_scene("heightfield:40", 96, 64)
+    a, ca = render(ctx, pt, sc, 4, seed=2)
+    b, cb = render(ctx, pt, sc, 4, seed=2, mode=pt.MODE_COUNT_STEPS)
+    assert ca.accel == cb.accel == pt.ACCEL_BVH
+    assert np.array_equal(a, b) and ca.segments == cb.segments
+    assert ca.node_steps == 0 and ca.leaf_steps == 0
+    assert cb.node_steps > cb.segments and 0 < cb.leaf_steps < cb.node_steps
+    print("nodes opened per segment %.2f, leaves tested per segment %.2f" % (
+        cb.node_steps / cb.segments, cb.leaf_steps / cb.segments))
+
+
 def test_render_is_deterministic_and_ranges_add_up(ctx, pt):
     """Bitwise repeatable; disjoint sample ranges sum to the one-range image up to fp32
     addition order (the property the multi-GPU sample partition rests on)."""
