@@ -30,6 +30,9 @@
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
 #endif
+#ifndef M_PI_2
+#define M_PI_2 1.57079632679489661923
+#endif
 #ifndef M_PI_4
 #define M_PI_4 0.78539816339744830962
 #endif
@@ -112,6 +115,50 @@ void orc_camera_init(orc_camera *cam, const float pos[3], float rot_x, float rot
     cam->dof_on = 0;
     cam->dof_focal_length = 2.0f;   /* scene.hpp:25 defaults */
     cam->dof_aperture = 0.15f;
+}
+
+/* The interactive camera, camera.hpp:41-58 and :76-89, driven as the main loop drives it
+ * (handle_input's rotate and move, main.cpp:178-203, then update, main.cpp:259) for n steps
+ * from the stored pose (pos, rot).  moves: n x 5 = d_rot_x, d_rot_y, dx, dy, dz.  out: n x 15 =
+ * pos (3), rot (2), update()'s return value, rotation matrix (9) after each step.
+ * cos and sin take their double forms as in rotation_matrix above; 2*M_PI and the yaw
+ * comparisons are double, the stores narrow to float. */
+void orc_camera_walk(const float pos0[3], const float rot0[2], int n, const float *moves, float *out)
+{
+    float pos[3] = {pos0[0], pos0[1], pos0[2]}, rot[2] = {rot0[0], rot0[1]};
+    float matrix[9];
+    int dirty = 0;
+    rotation_matrix(rot[0], rot[1], matrix);
+    for (int k = 0; k < n; k++) {
+        const float *m = moves + 5 * k;
+        if (!(m[0] == 0 && m[1] == 0)) {                      /* rotate, camera.hpp:41-48 */
+            rot[0] += m[0];
+            rot[1] += m[1];
+            dirty = 1;
+        }
+        if (!(m[2] == 0 && m[3] == 0 && m[4] == 0)) {         /* move, camera.hpp:50-58 */
+            const double c = cos((double)-rot[1]), sn = sin((double)-rot[1]);
+            pos[0] = (float)(pos[0] + (m[2] * c - m[4] * sn));
+            pos[2] = (float)(pos[2] + (m[2] * sn + m[4] * c));
+            pos[1] += m[3];
+            dirty = 1;
+        }
+        int updated = 0;
+        if (dirty) {                                          /* update, camera.hpp:76-89 */
+            dirty = 0;
+            updated = 1;
+            rotation_matrix(rot[0], rot[1], matrix);          /* before the clamp and the wrap */
+            const float lo = (float)-M_PI_2, hi = (float)M_PI_2;
+            rot[0] = rot[0] < lo ? lo : (hi < rot[0] ? hi : rot[0]);     /* glm::clamp = min(max(x, lo), hi) */
+            while (rot[1] > 2 * M_PI) rot[1] = (float)(rot[1] - 2 * M_PI);
+            while (rot[1] < 0) rot[1] = (float)(rot[1] + 2 * M_PI);
+        }
+        float *o = out + 15 * k;
+        o[0] = pos[0]; o[1] = pos[1]; o[2] = pos[2];
+        o[3] = rot[0]; o[4] = rot[1];
+        o[5] = (float)updated;
+        memcpy(o + 6, matrix, sizeof matrix);
+    }
 }
 
 /* main.cpp:50-54.  SCREEN_WIDTH/2 and SCREEN_HEIGHT/2 are integer divisions. */

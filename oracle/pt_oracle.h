@@ -8,7 +8,7 @@
  * PARITY: the reference (jvgille/Path-Tracer) ships no tests or golden vectors
  * for this path, and it cannot be built in this image (it needs GLM and SDL
  * 1.2, neither of which is present).  What it does ship are five images of its
- * own renderer (images/*.png): this oracle reproduces them - silhouettes for
+ * own renderer (the PNG files under images/): this oracle reproduces them - silhouettes for
  * 99.9 % of the pixels, block means within the images' own noise, mean levels
  * to 0.02-0.3 of a grey level - tests/test_reference_images.py.  That pins
  * camera, scene data, surface tests, samplers, weights and the tone map at
@@ -87,6 +87,9 @@ typedef struct orc_counters {
 
 /* camera.hpp:20-27,34-39: builds rot from (rot_x, rot_y); add_offset != 0
  * adds OFFSET = (2e-5, 1e-5) as the 3-argument constructor does. */
+/* camera.hpp:41-58,76-89: rotate, move, update for n steps; see pt_oracle.c. */
+void orc_camera_walk(const float pos0[3], const float rot0[2], int n, const float *moves, float *out);
+
 void orc_camera_init(orc_camera *cam, const float pos[3], float rot_x, float rot_y,
                      float focal, int add_offset, int width, int height);
 

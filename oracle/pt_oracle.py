@@ -116,6 +116,17 @@ def camera_init(pos, rot_x, rot_y, focal, add_offset, width, height):
     return cam
 
 
+def camera_walk(pos, rot, moves):
+    """camera.hpp's rotate / move / update for every row of moves (d_rot_x, d_rot_y, dx, dy, dz)
+    from the stored pose: rows of pos (3), rot (2), update()'s result, matrix (9)."""
+    pos = np.ascontiguousarray(pos, dtype=np.float32)
+    rot = np.ascontiguousarray(rot, dtype=np.float32)
+    moves = np.ascontiguousarray(moves, dtype=np.float32).reshape(-1, 5)
+    out = np.empty((len(moves), 15), dtype=np.float32)
+    lib().orc_camera_walk(_p(pos), _p(rot), C.c_int(len(moves)), _p(moves), _p(out))
+    return out
+
+
 def primary_hits(scene):
     n = scene.width * scene.height
     idx = np.empty(n, dtype=np.int32)

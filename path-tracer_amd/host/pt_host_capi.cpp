@@ -121,4 +121,26 @@ void pt_host_camera_matrix(float rot_x, float rot_y, int add_offset, float out_r
     }
 }
 
+// class Camera driven as the main loop drives it: rotate, move (handle_input) and update for
+// n steps from the stored pose.  moves: n x 5 = d_rot_x, d_rot_y, dx, dy, dz.  out: n x 15 =
+// position, rotation, update()'s result, rotation matrix (column-major) after each step.
+void pt_host_camera_walk(const float pos0[3], const float rot0[2], int n, const float *moves, float *out)
+{
+    Camera cam = Camera::from_pose(vec3(pos0[0], pos0[1], pos0[2]), vec2(rot0[0], rot0[1]), 1.0f);
+    for (int k = 0; k < n; k++) {
+        const float *m = moves + 5 * k;
+        cam.rotate(m[0], m[1]);
+        cam.move(m[2], m[3], m[4]);
+        const bool updated = cam.update();
+        float *o = out + 15 * k;
+        const vec3 &p = cam.get_position();
+        const vec2 &r = cam.get_rotation();
+        o[0] = p.x; o[1] = p.y; o[2] = p.z;
+        o[3] = r.x; o[4] = r.y;
+        o[5] = updated ? 1.0f : 0.0f;
+        const mat3 &rm = cam.get_rotation_matrix();
+        for (int c = 0; c < 3; c++) { o[6 + 3 * c] = rm[c].x; o[7 + 3 * c] = rm[c].y; o[8 + 3 * c] = rm[c].z; }
+    }
+}
+
 }  // extern "C"

@@ -61,34 +61,33 @@ struct Logging {
     unsigned next_target = 100;
 };
 
-// src/main.cpp:170-251.  dt in milliseconds.  Returns true when the image must
-// restart (a depth-of-field key was held, whether or not the value changed).
-// Camera motion reports through Camera::update(), as in the reference.
+// The key bindings of src/main.cpp:170-251 as data.  Every control is a pair of keys; the
+// first wins when both are held (the reference's `if ... else if`).
+struct KeyPair { Key first, second; };
+constexpr KeyPair PITCH_KEYS = {KEY_UP, KEY_DOWN}, YAW_KEYS = {KEY_RIGHT, KEY_LEFT};
+constexpr KeyPair STRAFE_KEYS = {KEY_D, KEY_A}, LIFT_KEYS = {KEY_Q, KEY_E}, WALK_KEYS = {KEY_W, KEY_S};
+constexpr KeyPair SAVING_KEYS = {KEY_1, KEY_2}, DOF_KEYS = {KEY_U, KEY_J};
+constexpr KeyPair FOCAL_KEYS = {KEY_I, KEY_K}, APERTURE_KEYS = {KEY_O, KEY_L};
+constexpr float FOCAL_STEP = 0.1f, APERTURE_STEP = 0.01f;      // src/main.cpp:228-247
+
+// +1 when the pair's first key is held, -1 when only its second is, 0 when neither.
+inline int pair_sign(const KeyState &keys, KeyPair p) { return keys[p.first] ? 1 : keys[p.second] ? -1 : 0; }
+
+// One frame's worth of input (src/main.cpp:170-251).  dt in milliseconds; speeds are one
+// unit (radian) per second.  Returns true when the image must restart because a
+// depth-of-field key was held, whether or not a value changed; camera motion reports
+// through Camera::update(), as in the reference.
 inline bool handle_input(Scene &scene, float dt, const KeyState &keys, Logging &logging, std::ostream &msg = std::cerr)
 {
-    const float MOVE_SPEED = 1 * dt / 1000;
-    const float ROT_SPEED = 1 * dt / 1000;
-    bool invalidate_buffer = false;
+    const float step = 1 * dt / 1000;
+    scene.camera.rotate(pair_sign(keys, PITCH_KEYS) * step, pair_sign(keys, YAW_KEYS) * step);
+    scene.camera.move(pair_sign(keys, STRAFE_KEYS) * step, pair_sign(keys, LIFT_KEYS) * step,
+                      pair_sign(keys, WALK_KEYS) * step);
 
-    float d_rot_x = 0, d_rot_y = 0;
-    if (keys[KEY_UP]) d_rot_x = ROT_SPEED;
-    else if (keys[KEY_DOWN]) d_rot_x = -ROT_SPEED;
-    if (keys[KEY_RIGHT]) d_rot_y = ROT_SPEED;
-    else if (keys[KEY_LEFT]) d_rot_y = -ROT_SPEED;
-    scene.camera.rotate(d_rot_x, d_rot_y);
-
-    float dx = 0, dy = 0, dz = 0;
-    if (keys[KEY_D]) dx = MOVE_SPEED;
-    else if (keys[KEY_A]) dx = -MOVE_SPEED;
-    if (keys[KEY_Q]) dy = MOVE_SPEED;
-    else if (keys[KEY_E]) dy = -MOVE_SPEED;
-    if (keys[KEY_W]) dz = MOVE_SPEED;
-    else if (keys[KEY_S]) dz = -MOVE_SPEED;
-    scene.camera.move(dx, dy, dz);
-
-    if (keys[KEY_1]) { msg << "image saving enabled" << std::endl; logging.save_image = true; }
-    else if (keys[KEY_2]) { msg << "image saving disabled" << std::endl; logging.save_image = false; }
-
+    if (const int saving = pair_sign(keys, SAVING_KEYS)) {
+        logging.save_image = saving > 0;
+        msg << (saving > 0 ? "image saving enabled" : "image saving disabled") << std::endl;
+    }
     if (keys[KEY_0]) {
         const vec3 &p = scene.camera.get_position();
         const vec2 &r = scene.camera.get_rotation();
@@ -97,18 +96,23 @@ inline bool handle_input(Scene &scene, float dt, const KeyState &keys, Logging &
         std::cout << buf << std::endl;
     }
 
-    if (keys[KEY_U]) { invalidate_buffer = true; scene.DOF_on = true; msg << "depth of field enabled" << std::endl; }
-    else if (keys[KEY_J]) { invalidate_buffer = true; scene.DOF_on = false; msg << "depth of field disabled" << std::endl; }
-
-    if (keys[KEY_I]) { invalidate_buffer = true; scene.DOF_focal_length += 0.1f; }
-    else if (keys[KEY_K]) { invalidate_buffer = true; scene.DOF_focal_length -= 0.1f; }
-    if (keys[KEY_I] || keys[KEY_K]) msg << "DoF focal length: " << scene.DOF_focal_length << std::endl;
-
-    if (keys[KEY_O]) { invalidate_buffer = true; scene.DOF_aperture_size += 0.01f; }
-    else if (keys[KEY_L]) { invalidate_buffer = true; scene.DOF_aperture_size -= 0.01f; }
-    if (keys[KEY_O] || keys[KEY_L]) msg << "DoF aperture size: " << scene.DOF_aperture_size << std::endl;
-
-    return invalidate_buffer;
+    bool restart = false;
+    if (const int dof = pair_sign(keys, DOF_KEYS)) {
+        restart = true;
+        scene.DOF_on = dof > 0;
+        msg << (dof > 0 ? "depth of field enabled" : "depth of field disabled") << std::endl;
+    }
+    if (const int focal = pair_sign(keys, FOCAL_KEYS)) {
+        restart = true;
+        if (focal > 0) scene.DOF_focal_length += FOCAL_STEP; else scene.DOF_focal_length -= FOCAL_STEP;
+        msg << "DoF focal length: " << scene.DOF_focal_length << std::endl;
+    }
+    if (const int aperture = pair_sign(keys, APERTURE_KEYS)) {
+        restart = true;
+        if (aperture > 0) scene.DOF_aperture_size += APERTURE_STEP; else scene.DOF_aperture_size -= APERTURE_STEP;
+        msg << "DoF aperture size: " << scene.DOF_aperture_size << std::endl;
+    }
+    return restart;
 }
 
 // A 24-bit uncompressed BMP (bottom-up rows of B,G,R padded to four bytes), the

@@ -41,6 +41,39 @@ def test_camera_matrix_equals_oracle(pt, orc):
             assert out.tobytes() == want.tobytes(), (rx, ry, off)
 
 
+def test_camera_walk_equals_oracle(pt, orc):
+    """Camera::rotate / move / update (src/camera.hpp:41-58, 76-89) in the C++ mirror against the
+    oracle's restatement, driven as the main loop drives them, bit for bit: random walks, steps
+    that change nothing, pitch past the clamp, yaw below 0 and beyond 2 pi."""
+    host = pt.load_host()
+    rng = np.random.default_rng(8)
+
+    def walk(pos, rot, moves):
+        pos = np.float32(pos)
+        rot = np.float32(rot)
+        moves = np.ascontiguousarray(moves, dtype=np.float32).reshape(-1, 5)
+        out = np.empty((len(moves), 15), dtype=np.float32)
+        host.pt_host_camera_walk(C.c_void_p(pos.ctypes.data), C.c_void_p(rot.ctypes.data), C.c_int(len(moves)),
+                                 C.c_void_p(moves.ctypes.data), C.c_void_p(out.ctypes.data))
+        return out, orc.camera_walk(pos, rot, moves)
+
+    for trial in range(20):
+        moves = rng.normal(0, 0.3, (200, 5)).astype(np.float32)
+        moves[rng.random(200) < 0.3, :2] = 0          # frames without rotation
+        moves[rng.random(200) < 0.3, 2:] = 0          # frames without motion
+        got, want = walk(rng.uniform(-3, 3, 3), rng.uniform(-1, 1, 2), moves)
+        assert got.tobytes() == want.tobytes(), trial
+        assert (got[:, 5] == (moves != 0).any(axis=1)).all()      # update() reports exactly the frames that changed something
+    # the clamp and the wrap act on the stored pose after the matrix was built from the raw one
+    got, want = walk([0, 0, 0], [1.5, 0.1], [[0.5, -0.3, 0, 0, 0], [0, 0, 0, 0, 0], [0.0, 7.0, 1, 0, 1]])
+    assert got.tobytes() == want.tobytes()
+    assert got[0, 3] == np.float32(np.pi / 2) and got[0, 4] == np.float32(float(np.float32(0.1) + np.float32(-0.3)) + 2 * np.pi)
+    raw = orc.camera_init([0, 0, 0], np.float32(2.0), np.float32(0.1) + np.float32(-0.3), 1.0, 0, 8, 8)["rot"][0]
+    assert got[0, 6:].tobytes() == raw.tobytes()                 # pitch 2.0 in the matrix, pi/2 in the pose
+    assert got[1, 5] == 0 and got[1, :5].tobytes() == got[0, :5].tobytes()
+    assert 0 <= got[2, 4] <= np.float32(2 * np.pi)
+
+
 def test_scene_files_round_trip(pt, tmp_path):
     """save_scene -> load_scene reproduces every flattened scene bit for bit."""
     for name in list(pt.SCENE_NAMES) + ["glass_stress", "heightfield:12"]:
