@@ -386,7 +386,8 @@ PT_DEV void bvh_test_leaf(BvhCursor &c, const BvhView &bvh, float4 g0, float4 g1
     const bool det_bad = __builtin_fabsf(q.det_a) <= EPS_F;
     const float dist = t * c.len_d;
     if constexpr (FAST) {
-        const bool acc = !(det_bad | (u < -EPS_F) | (u >= 1.0f) | (v < -EPS_F) | (s >= 1.0f) | (t <= EPS_F));
+        // (t by a positive compare: a NaN is no hit)
+        const bool acc = !(det_bad | (u < -EPS_F) | (u >= 1.0f) | (v < -EPS_F) | (s >= 1.0f)) & (t > EPS_F);
         if (acc & (dist < best.lo)) best = {idx, dist, t};
     } else {
         // the same bands as the scan's filter (scan_surface)

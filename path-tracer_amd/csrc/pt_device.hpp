@@ -147,7 +147,7 @@ constexpr int GEOM_TRIANGLE = 0, GEOM_SPHERE = 1;
 // v_rcp_f32 flushes a denormal result to zero) carries a NaN in element 7: every
 // estimate the error-band filter forms for it is then a NaN, no band decides,
 // and the ray is evaluated by closest_direct, which computes that minor itself.
-// (The FAST policy has no such fallback: it does not see these triangles.)
+// (The FAST policy has no such fallback: the NaN fails its test of t, and the triangle is never hit.)
 constexpr float GEOM_DIRECT_EDGE_PRODUCT = 1e18f;     // |e1|max * |e2|max above this
 
 // Shading record, 12 floats per surface, read with per-lane indices.
@@ -539,7 +539,8 @@ PT_DEV void scan_surface(Scan &st, int i, const GeomRec &rec, V3 o, V3 d)
         const float dist = t * len_d;
         if constexpr (FAST) {
             rej = det_bad | PT_B(u >= 1.0f) | PT_B(s >= 1.0f);
-            rej = or_le<f32_bits(EPS_F)>(or_lt<f32_bits(-EPS_F)>(or_lt<f32_bits(-EPS_F)>(rej, u), v), t);
+            // t by a positive compare: a NaN (an extreme triangle's record, a non-finite ray) is no hit
+            rej = or_lt<f32_bits(-EPS_F)>(or_lt<f32_bits(-EPS_F)>(rej, u), v) | ~PT_B(t > EPS_F);
             acc = ~rej;
             c_lo = c_hi = dist;
         } else {
@@ -694,7 +695,8 @@ PT_DEV Hit closest_intersection(cfloat_p geom, int n_surfaces, V3 o, V3 d,
 // (src/surface.hpp:53-66) become one signed margin, positive inside:
 //     min(min(u, v) + eps, 1 - (u + v), t - eps, |n.d| - eps / |N|)
 // (u < 1 follows from the other two), one comparison.  A NaN anywhere (a degenerate
-// triangle's record, a non-finite ray) fails that comparison: no hit.
+// triangle's record, a non-finite ray, a hit point that overflows) is carried into the
+// margin and fails that comparison: no hit.
 //
 // Lean record, 16 floats per surface, scene order, read with wave-uniform indices:
 //  triangle: [0..2] n  [3] kind  [4] d0  [5..7] Ku  [8] cu  [9..11] Kv  [12] run  [13] cv  [14] eps / |N|
@@ -733,7 +735,8 @@ PT_DEV void lean_triangle(LeanBest &best, int i, const LeanRec &r, V3 o, V3 d, f
     const float v = __builtin_fmaf(r.q2.w, pz, __builtin_fmaf(r.q2.z, py, __builtin_fmaf(r.q2.y, px, r.q3.y)));
     const float inside = __builtin_fminf(__builtin_fminf(u, v) + EPS_F, 1.0f - (u + v));
     const float ahead = __builtin_fminf(t - EPS_F, __builtin_fabsf(den) - r.q3.z);
-    const float margin = __builtin_fminf(inside, ahead);          // min3 + min
+    // (min drops a NaN operand: 0 * (u + v) carries a NaN or an overflowed hit point into the margin)
+    const float margin = __builtin_fmaf(u + v, 0.0f, __builtin_fminf(inside, ahead));
     const float dist = t * len_d;
     if (margin > 0.0f && dist < best.dist) best = {4 * i, dist};
 }

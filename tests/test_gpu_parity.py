@@ -810,6 +810,18 @@ def test_extreme_magnitudes_and_non_finite_inputs(ctx, pt, orc):
                 accel, bad.size, bad[0], got[0][bad[0]], want[0][bad[0]])
             assert np.array_equal(got[1], want[1], equal_nan=True)
             assert np.array_equal(got[2], want[2], equal_nan=True)
+        # The FAST policy on the same scene (its triangles include extreme ones, whose records carry
+        # NaNs): a NaN never counts as a hit, whichever scan evaluates it - plane equations through the
+        # scalar cache, fused determinants through the LDS tiles and in the hierarchy's leaves.
+        finite = np.isfinite(o).all(1) & np.isfinite(d).all(1)
+        ordinary = finite & (np.abs(o).max(1) < 1e3) & (np.abs(d).max(1) < 1e3) & (np.abs(d).max(1) > 1e-4)
+        for accel in (pt.ACCEL_NONE, pt.ACCEL_LDS_TILES, pt.ACCEL_BVH):
+            ctx.set_accel(accel)
+            ctx.set_scene(surf, mats, [0, 0, 0])
+            fi, fd, fp = ctx.intersect_rays(o[ordinary], d[ordinary], pt.NUM_FAST)
+            hit = (fi >= 0) & (surf["kind"][np.maximum(fi, 0)] == pt.TRIANGLE)
+            assert hit.sum() > 300
+            assert np.isfinite(fd[hit]).all(), accel
     finally:
         ctx.set_accel(pt.ACCEL_AUTO)
     assert (want[0] >= 0).sum() > 3000 and len(np.unique(want[0])) > 15
