@@ -431,7 +431,12 @@ static inline uint32_t pcg(uint32_t v)
     return (w >> 22) ^ w;
 }
 
-typedef struct { uint32_t key, ctr; } rng_t;
+/* The counter-based generator the HIP path uses in place of libc rand() (a design change: the
+ * reference's generator is serial global state).  key = pcg(pcg(seed ^ pixel) ^ sample * G),
+ * draw i = pcg(key ^ i * G): neither level is additive, so paths whose keys meet or lie close
+ * do not replay each other in runs. */
+#define RNG_STEP 0x9E3779B9u
+typedef struct { uint32_t key, ctr; } rng_t;       /* ctr = RNG_STEP * draws made so far */
 
 static inline uint32_t seed_mix(uint64_t seed)
 {
@@ -441,18 +446,23 @@ static inline uint32_t seed_mix(uint64_t seed)
 static inline rng_t rng_path(uint32_t smix, uint32_t pixel, uint32_t sample)
 {
     rng_t r;
-    r.key = pcg(pcg(smix ^ pixel) + sample);
+    r.key = pcg(pcg(smix ^ pixel) ^ (sample * RNG_STEP));
     r.ctr = 0;
     return r;
 }
 
 static inline float rng_at(const rng_t *r, uint32_t draw)
 {
-    uint32_t x = pcg(r->key + draw);
+    uint32_t x = pcg(r->key ^ (r->ctr + draw * RNG_STEP));
     return (float)((x >> 8) | 1u) * 0x1p-24f;    /* odd/2^24: in (0,1), exact */
 }
 
-static inline double rng_next(rng_t *r) { return (double)rng_at(r, r->ctr++); }
+static inline double rng_next(rng_t *r)
+{
+    double x = (double)rng_at(r, 0);
+    r->ctr += RNG_STEP;
+    return x;
+}
 
 float orc_rng_uniform(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t draw)
 {

@@ -99,6 +99,14 @@ struct Num {
 // of a path is a pure function of (seed, pixel, sample); draw i of the path is
 // a pure function of the stream and i.  Values are odd multiples of 2^-24, so
 // they lie strictly inside (0,1).
+//
+// Neither level is additive: the stream's key is pcg(pixel_key ^ sample * G) and draw i is
+// pcg(key ^ i * G), G = 2^32 / golden ratio.  With sums in place of the exclusive-ors, two
+// pixels whose keys lie less than spp apart (some 10^5 pairs in an 800 x 800 image) would trace
+// hundreds of identical paths at shifted sample numbers, and two paths with neighbouring keys
+// would draw each other's numbers a few draws later; as it is, the 32-bit keys of an image's
+// 10^9 paths still meet now and then (the birthday bound), but scattered over all pixel pairs,
+// one path at a time.
 
 PT_DEV uint32_t pcg(uint32_t v)
 {
@@ -107,7 +115,9 @@ PT_DEV uint32_t pcg(uint32_t v)
     return (w >> 22) ^ w;
 }
 
-struct Rng { uint32_t key, ctr; };
+constexpr uint32_t RNG_STEP = 0x9E3779B9u;
+
+struct Rng { uint32_t key, ctr; };      // ctr = RNG_STEP * (draws made so far)
 
 // Per-pixel part of the key: computed once per work item.
 PT_DEV uint32_t rng_pixel(uint32_t seed_mix, uint32_t pixel) { return pcg(seed_mix ^ pixel); }
@@ -115,18 +125,23 @@ PT_DEV uint32_t rng_pixel(uint32_t seed_mix, uint32_t pixel) { return pcg(seed_m
 PT_DEV Rng rng_path(uint32_t pixel_key, uint32_t sample)
 {
     Rng r;
-    r.key = pcg(pixel_key + sample);
+    r.key = pcg(pixel_key ^ (sample * RNG_STEP));
     r.ctr = 0;
     return r;
 }
 
 PT_DEV float rng_at(const Rng &r, uint32_t draw)
 {
-    const uint32_t x = pcg(r.key + draw);
+    const uint32_t x = pcg(r.key ^ (r.ctr + draw * RNG_STEP));
     return (float)((x >> 8) | 1u) * 0x1p-24f;
 }
 
-PT_DEV float rng_next(Rng &r) { return rng_at(r, r.ctr++); }
+PT_DEV float rng_next(Rng &r)
+{
+    const uint32_t x = pcg(r.key ^ r.ctr);
+    r.ctr += RNG_STEP;
+    return (float)((x >> 8) | 1u) * 0x1p-24f;
+}
 
 // ---------------------------------------------------------------- scene records
 
