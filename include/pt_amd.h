@@ -143,7 +143,13 @@ int pt_set_scene(pt_ctx *ctx, const pt_surface *surfaces, int32_t n_surfaces,
  * The reference scans every surface for every segment (src/main.cpp:58-66;
  * an "octree" is a to-do note, src/main.cpp:75).  The hierarchy, built on the
  * GPU over the scene's small triangles, returns the same surface, t and
- * distance as the scan, ties included. */
+ * distance as the scan, ties included: candidates are evaluated in the
+ * reference's arithmetic, and the boxes are padded for what that arithmetic
+ * accepts outside a triangle (its 1e-5 tolerances, and the error of its u and
+ * v for rays nearly parallel to a triangle, where its determinant is just
+ * above the 1e-5 cut-off).  Checked on random scenes against the scan, rays
+ * aimed at edges, vertices and along triangle planes included
+ * (tools/soak_parity.py). */
 int pt_set_accel(pt_ctx *ctx, int accel);
 
 /* Ends every path of later renders after max_segments closest-hit queries

@@ -18,6 +18,7 @@ namespace ptd {
 constexpr int BVH_NODE_QUADS = 4;
 constexpr int BVH_MAX_LEAVES = 1 << 25;          // nodes + leaves, 64 bytes each, within 4 GiB
 constexpr float BVH_ORIGIN_ROUNDING = 8e-6f;     // of |o|: some 60 ulps
+constexpr float BVH_GRAZING = 0.05f;             // some 8 eps / 1e-5
 // A leaf is one triangle: its geometry record (GEOM_STRIDE floats) with the
 // surface's index in scene order in element 3 (where a geometry record keeps the kind).
 constexpr int BVH_STACK = 64;        // deepest possible tree: one level per key bit
@@ -81,7 +82,15 @@ k_bvh_prepare(const float *geom, const int *tri_idx, int n, float3 cmin, float3 
     V3 hi = v3(fmaxf(v0.x, fmaxf(v1.x, v2.x)), fmaxf(v0.y, fmaxf(v1.y, v2.y)), fmaxf(v0.z, fmaxf(v1.z, v2.z)));
     const float size = (hi.x - lo.x) + (hi.y - lo.y) + (hi.z - lo.z);
     const float reach = fmaxf(fmaxf(fabsf(lo.x), fabsf(hi.x)), fmaxf(fmaxf(fabsf(lo.y), fabsf(hi.y)), fmaxf(fabsf(lo.z), fabsf(hi.z))));
-    const float pad = 1e-3f * size + 1e-5f * (1.0f + reach) + BVH_ORIGIN_ROUNDING * ray_reach;
+    // ... and for rays nearly parallel to the triangle's plane: the reference accepts any
+    // |determinant| above 1e-5, and its fp32 u and v then carry an error of some
+    // eps |o - v0| |e1| |e2| / 1e-5 edge lengths, so a hit it reports can lie that far off the
+    // triangle: BVH_GRAZING * (ray_reach + reach) * |e1| |e2| * longest edge (negligible for small
+    // triangles).
+    const V3 e1 = v3(g[4], g[5], g[6]), e2 = v3(g[8], g[9], g[10]), e3 = e2 - e1;
+    const float l1 = sqrtf(Num<true>::dot(e1, e1)), l2 = sqrtf(Num<true>::dot(e2, e2)), l3 = sqrtf(Num<true>::dot(e3, e3));
+    const float pad = 1e-3f * size + 1e-5f * (1.0f + reach) + BVH_ORIGIN_ROUNDING * ray_reach +
+                      BVH_GRAZING * (ray_reach + reach) * l1 * l2 * fmaxf(l1, fmaxf(l2, l3));
     box_min[j] = make_float4(lo.x - pad, lo.y - pad, lo.z - pad, 0.0f);
     box_max[j] = make_float4(hi.x + pad, hi.y + pad, hi.z + pad, 0.0f);
     const float cx = ((lo.x + hi.x) * 0.5f - cmin.x) * cinv.x;

@@ -49,6 +49,28 @@ for seed in range(seeds):
     i0, _, p0 = orc.intersect_rays(osc, o[m // 3:2 * m // 3], d[m // 3:2 * m // 3])
     hit = i0 >= 0
     o[m // 3:2 * m // 3][hit] = p0[hit]
+    # a sixth of the rays run nearly parallel to a triangle's plane from far away, so that the
+    # reference's determinant lies just above its 1e-5 threshold (1e-5 .. 1e-3), where its
+    # fp32 u, v and t are least accurate and a hit can lie well off the triangle
+    g = m // 6
+    tri = np.flatnonzero(surf["kind"] == pt.TRIANGLE)
+    if len(tri):
+        k = rng.choice(tri, g)
+        e1, e2 = (surf["b"][k] - surf["a"][k]).astype(np.float64), (surf["c"][k] - surf["a"][k]).astype(np.float64)
+        nrm = np.cross(e1, e2)
+        area2 = np.linalg.norm(nrm, axis=1, keepdims=True) + 1e-30
+        nrm /= area2
+        w = rng.uniform(-0.1, 1.1, (g, 2))
+        point = surf["a"][k] + w[:, :1] * e1 + w[:, 1:] * (1 - w[:, :1]) * e2
+        phi = rng.uniform(0, 2 * np.pi, (g, 1))
+        e1n = e1 / (np.linalg.norm(e1, axis=1, keepdims=True) + 1e-30)
+        in_plane = np.cos(phi) * e1n + np.sin(phi) * np.cross(nrm, e1n)
+        det = 10.0 ** rng.uniform(-5.3, -3.0, (g, 1)) * rng.choice([-1.0, 1.0], (g, 1))      # |d . N| wanted
+        dirs = in_plane + (det / area2) * nrm
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        far = rng.choice([2.0, 5.0, 10.0, 20.0], (g, 1)) * spread
+        o[-g:] = (point - far * dirs).astype(np.float32)
+        d[-g:] = dirs.astype(np.float32)
     want = orc.intersect_rays(osc, o, d)
     for accel in (pt.ACCEL_NONE, pt.ACCEL_BVH, pt.ACCEL_LDS_TILES):
         ctx.set_accel(accel)
