@@ -330,7 +330,10 @@ inline void trace_rays(Scene &scene, BUFFER &buffer, uint32_t spp = 1)
     const float *sums = r.map_sums();
     // the device image is row-major, BUFFER is a vector of columns: a few columns at a
     // time, so that a row's pixels are read while their cache lines are still there
+    // (column blocks are independent: spread over the host's cores when built with OpenMP, which
+    // the reference links too, CMakeLists.txt:7)
     constexpr int COLUMNS = 16;
+#pragma omp parallel for schedule(static)
     for (int u0 = 0; u0 < width; u0 += COLUMNS) {
         const int u1 = u0 + COLUMNS < width ? u0 + COLUMNS : width;
         for (int v = 0; v < height; v++) {
