@@ -332,9 +332,11 @@ PT_DEV TriDets bvh_leaf_dets(const BvhView &bvh, int leaf, V3 o, V3 d, int &scen
 
 // After the traversal: the closest hit overall, with the reference's t and
 // distance (idx < 0: none).  geom, n_surfaces: every surface's geometry record.
+// outside_t: the ray parameter of the hit outside the hierarchy the traversal
+// began with (bvh_best_from), which is the answer when no leaf came closer.
 template <bool FAST>
 PT_DEV Hit bvh_finish(const BvhCursor &c, const BvhView &bvh, const float *geom, int n_surfaces, V3 o, V3 d,
-                      const BvhBest &best)
+                      const BvhBest &best, float outside_t)
 {
     Hit h = {-1, 0.0f, 0.0f};
     if constexpr (FAST) {
@@ -344,11 +346,8 @@ PT_DEV Hit bvh_finish(const BvhCursor &c, const BvhView &bvh, const float *geom,
         if (c.direct) return closest_direct<false>(as_constant(geom), n_surfaces, o, d);
         if (best.ref == BVH_NO_HIT) return h;
         if (best.ref >= 0) {
-            // a surface outside the hierarchy won: its t again (its distance is best.lo)
-            cfloat_p g = as_constant(geom + (size_t)best.ref * GEOM_STRIDE);
-            h.idx = best.ref;
-            if (__builtin_bit_cast(int, g[3]) == GEOM_TRIANGLE) triangle_direct<false>(g, o, d, -d, h.t, h.dist);
-            else sphere_direct<false>(g, o, d, h.t, h.dist);
+            // a surface outside the hierarchy won: the scan that found it has its exact t and distance
+            h = {best.ref, outside_t, best.lo};
         } else {
             const TriDets q = bvh_leaf_dets(bvh, ~best.ref, o, d, h.idx);
             bvh_leaf_exact(q, d, h.t, h.dist);
@@ -536,9 +535,10 @@ PT_DEV void closest_in_bvh(const BvhView &bvh, const float *geom, int n_surfaces
     BvhCursor c;
     bvh_begin<FAST>(c, bvh, o, d, hit);
     BvhBest best = bvh_best_from<FAST>(hit);
+    const float outside_t = hit.t;
     if (!c.direct)
         while (bvh_step<FAST>(c, bvh, o, d, best, stack, stride)) {}
-    hit = bvh_finish<FAST>(c, bvh, geom, n_surfaces, o, d, best);
+    hit = bvh_finish<FAST>(c, bvh, geom, n_surfaces, o, d, best, outside_t);
 }
 
 }  // namespace ptd

@@ -595,7 +595,9 @@ k_render_mega_bvh(RenderParams P)
     BvhBest best = {BVH_NO_HIT, 0.0f, 0.0f};
     BvhCursor cur;
     cur.node = 0; cur.sp = 0; cur.top = 0; cur.inv = v3(0, 0, 0); cur.len_d = 1.0f; cur.inv_len = 1.0f; cur.slack = 0.0f; cur.direct = false;
-    int stack[BVH_STACK];
+    // the traversal stack, and behind it the ray parameter of the segment's hit outside the
+    // hierarchy: needed once, after the traversal, so it waits in memory, not in a register
+    int stack[BVH_STACK + 1];
     bool alive = true;              // false: the queue is empty and this lane has nothing left
     bool traversing = false;        // false: waiting to shade / start a segment
     bool have_hit = false;          // a finished segment waits to be shaded
@@ -613,7 +615,8 @@ k_render_mega_bvh(RenderParams P)
                 need_path = !have_hit;
                 if (have_hit) {
                     // the winner's t and distance, once per segment (bvh_finish), then shading
-                    Hit h = bvh_finish<FAST>(cur, P.scene.bvh, P.scene.geom, P.scene.n_surfaces, ps.o, ps.d, best);
+                    Hit h = bvh_finish<FAST>(cur, P.scene.bvh, P.scene.geom, P.scene.n_surfaces, ps.o, ps.d, best,
+                                             FAST ? 0.0f : __builtin_bit_cast(float, stack[BVH_STACK]));
                     if (h.idx < 0) h.dist = 0.0f;
                     if (shade_hit<FAST>(ps, P.scene, shade, h)) {
                         it.sum = it.sum + ps.col;            // buffer[u][v] += color, main.cpp:139
@@ -638,6 +641,7 @@ k_render_mega_bvh(RenderParams P)
                 Hit outside = closest_intersection<FAST, true>(as_constant(P.scene.loose_geom), P.scene.n_scan,
                                                                ps.o, ps.d, P.stats + 1);
                 if (outside.idx >= 0) outside.idx = P.scene.loose[outside.idx];
+                if constexpr (!FAST) stack[BVH_STACK] = __builtin_bit_cast(int, outside.t);
                 bvh_begin<FAST>(cur, P.scene.bvh, ps.o, ps.d, outside);
                 best = bvh_best_from<FAST>(outside);
                 traversing = true;
