@@ -458,6 +458,43 @@ def test_wavefront_equals_megakernel(ctx, pt, name):
     assert np.allclose(fast.mean((0, 1)), mega.mean((0, 1)), rtol=0.02)
 
 
+def test_headline_configuration_at_full_size(ctx, pt, golden):
+    """The benchmark's own launch (800 x 800 Cornell box, 1024 spp: 6.6e8 paths, 3.2e9 closest-hit
+    searches) through properties that do not need the oracle to finish it: the count of segments,
+    a checksum over every hit/miss and russian-roulette decision, is the same integer in both
+    kernel layouts and on a second run; the image is bitwise repeatable; two halves of the
+    samples add up to it; its mean level and path length agree with the converged golden image
+    of the reference's generator; the FAST policy lands within a percent of both."""
+    sc = pt.builtin_scene("cornell_2", 800, 800)
+    spp = 1024
+    mega, cm = render(ctx, pt, sc, spp, seed=1, mode=pt.MODE_MEGAKERNEL)
+    again, ca = render(ctx, pt, sc, spp, seed=1, mode=pt.MODE_MEGAKERNEL)
+    assert cm.samples == 800 * 800 * spp and ca.segments == cm.segments
+    assert np.array_equal(mega, again)
+    wave, cw = render(ctx, pt, sc, spp, seed=1, mode=pt.MODE_WAVEFRONT)
+    assert cw.segments == cm.segments
+    assert np.allclose(wave, mega, rtol=2e-5, atol=1e-4)
+    load(ctx, sc)
+    ctx.render(spp // 2, 0, 1, 0)
+    ctx.render(spp // 2, spp // 2, 1, 0)
+    halves, total = ctx.read_accum()
+    assert total == spp and np.allclose(halves, mega, rtol=2e-5, atol=1e-4)
+    g = golden("render_libc_64_4096spp.npz")
+    want_mean = g["cornell_2_mean"].astype(np.float64).mean((0, 1))
+    got_mean = mega.astype(np.float64).mean((0, 1)) / spp
+    assert np.allclose(got_mean, want_mean, rtol=0.01), (got_mean, want_mean)
+    assert abs(cm.segments / cm.samples - float(g["cornell_2_segments_per_sample"])) < 0.01
+    fast, cf = render(ctx, pt, sc, spp, seed=1, mode=pt.MODE_MEGAKERNEL | pt.NUM_FAST)
+    assert abs(cf.segments / cf.samples - cm.segments / cm.samples) < 0.005
+    assert np.allclose(fast.astype(np.float64).mean((0, 1)), mega.astype(np.float64).mean((0, 1)), rtol=0.002)
+    # per pixel the two policies differ only where a decision flipped a path: a small fraction of pixels
+    diff = np.abs(fast.astype(np.float64) - mega).max(axis=2) / spp
+    rms = np.sqrt((diff ** 2).mean())
+    print("full size: %.4f segments/sample, mean %s, fast/exact rms %.4g, pixels that differ %.4f" % (
+        cm.segments / cm.samples, got_mean, rms, (diff > 1e-4).mean()))
+    assert rms < 0.05
+
+
 # ---------------------------------------------------------------- synthetic stress scenes
 
 def as_oracle_scene(orc, sc):
