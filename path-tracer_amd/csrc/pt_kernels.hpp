@@ -357,8 +357,9 @@ PT_DEV bool shade_hit(PathState &ps, const SceneView &sc, const float *shade, co
     V3 normal = v3(r2.x, r2.y, r2.z);
     if (flags >> 8) normal = S::normalize(point - normal);       // sphere, surface.hpp:86-88
     float xi0 = 0.0f, xi1 = 0.0f;
-    if (type == 0) { xi0 = rng_next(ps.rng); xi1 = rng_next(ps.rng); }
-    else if (type == 2) { xi0 = rng_next(ps.rng); }
+    // diffuse draws two numbers, glass one, a mirror none: the first draw in one block for both
+    if (type != 1) xi0 = rng_next(ps.rng);
+    if (type == 0) xi1 = rng_next(ps.rng);
     const V3 new_dir = sample_pdf<true>(type, normal, ps.d, xi0, xi1);
     ps.o = point;
     ps.col = v3(S::mad(r1.x, ps.thr.x, ps.col.x), S::mad(r1.y, ps.thr.y, ps.col.y),
