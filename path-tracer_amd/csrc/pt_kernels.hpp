@@ -43,11 +43,13 @@ constexpr int SCENE_BVH = 2;      // shading records from global memory, scan + 
 // lds: the kernel's dynamic LDS; a hierarchy scene keeps the traversal stacks
 // there, BVH_STACK levels of BLOCK lanes (level-major, so a level's 64 lanes
 // fall in 64 different banks).
-template <bool FAST, bool NEED_DIST, int KIND, bool WAVE_SKIP = false>
+// QUERY: called by a closest-hit query kernel, every wave of which runs the scan at the same time
+// (lean_triangle's PACKED).
+template <bool FAST, bool NEED_DIST, int KIND, bool WAVE_SKIP = false, bool QUERY = false>
 PT_DEV Hit closest_hit(const SceneView &sc, V3 o, V3 d, float *lds, unsigned long long *redo_count = nullptr)
 {
     if constexpr (KIND != SCENE_BVH) {
-        if constexpr (FAST) return closest_intersection_lean<WAVE_SKIP>(as_constant(sc.lean), sc.n_scan, o, d);
+        if constexpr (FAST) return closest_intersection_lean<WAVE_SKIP, QUERY>(as_constant(sc.lean), sc.n_scan, o, d);
         else return closest_intersection<FAST, NEED_DIST, WAVE_SKIP>(as_constant(sc.geom), sc.n_scan, o, d, redo_count);
     } else {
         Hit h = closest_intersection<FAST, true>(as_constant(sc.loose_geom), sc.n_scan, o, d, redo_count);
@@ -93,7 +95,7 @@ k_primary_hits(Camera cam, SceneView scene, int32_t *idx, float *dist)
     const V3 o = v3(cam.pos[0], cam.pos[1], cam.pos[2]);
     const V3 d = ray_direction_by_pixel<FAST>(cam, (float)x, (float)y);
     extern __shared__ __align__(16) float lds[];
-    const Hit h = closest_hit<FAST, true, KIND>(scene, o, d, lds);
+    const Hit h = closest_hit<FAST, true, KIND, false, true>(scene, o, d, lds);
     idx[p] = h.idx;
     dist[p] = h.idx < 0 ? 0.0f : h.dist;
 }
@@ -108,7 +110,7 @@ k_intersect_rays(SceneView scene, const float *org, const float *dir,
     const V3 o = v3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
     const V3 d = v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
     extern __shared__ __align__(16) float lds[];
-    const Hit h = closest_hit<FAST, true, KIND>(scene, o, d, lds);
+    const Hit h = closest_hit<FAST, true, KIND, false, true>(scene, o, d, lds);
     idx[i] = h.idx;
     dist[i] = h.idx < 0 ? 0.0f : h.dist;
     V3 pt = v3(0, 0, 0);
@@ -288,13 +290,15 @@ k_lean_records(const float *geom, int n, float *lean)
             cu -= ku[k] * v0[k];
             cv -= kv[k] * v0[k];
             out[k] = (float)(N[k] / len);
-            out[5 + k] = (float)ku[k];
-            out[9 + k] = (float)kv[k];
+            out[6 + 2 * k] = (float)ku[k];
+            out[7 + 2 * k] = (float)kv[k];
         }
         out[4] = (float)d0;
-        out[8] = (float)cu;
-        out[13] = (float)cv;
-        out[14] = (float)(1e-5 / len);  // |determinant(-d, e1, e2)| = |n.d| |N| against EPSILON (surface.hpp:53)
+        // |determinant(-d, e1, e2)| = |n.d| |N| against EPSILON (surface.hpp:53); the scan's margin is
+        // formed less eps throughout (lean_triangle)
+        out[5] = (float)(1e-5 / len + (double)EPS_F);
+        out[14] = (float)cu;
+        out[15] = (float)cv;
     } else {
         out[0] = g[0]; out[1] = g[1]; out[2] = g[2];
         out[4] = g[4];
