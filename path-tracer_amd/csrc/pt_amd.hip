@@ -96,6 +96,7 @@ struct pt_ctx {
     float bvh_ray_reach = 0.0f;
     int *d_loose = nullptr;
     float *d_loose_geom = nullptr;
+    float *d_loose_lean = nullptr;      // the FAST policy's records of the same surfaces, same order
     std::vector<pt_surface> host_surfaces;      // kept to rebuild when pt_set_accel changes
     float4 *d_bvh_nodes = nullptr;
     float *d_bvh_leaves = nullptr;
@@ -208,9 +209,11 @@ int build_hierarchy(pt_ctx *ctx, const pt_surface *surfaces, int n_surfaces)
 {
     if (ctx->d_loose) (void)hipFree(ctx->d_loose);
     if (ctx->d_loose_geom) (void)hipFree(ctx->d_loose_geom);
+    if (ctx->d_loose_lean) (void)hipFree(ctx->d_loose_lean);
     if (ctx->d_bvh_nodes) (void)hipFree(ctx->d_bvh_nodes);      // the leaves live in the same allocation
     ctx->d_loose = nullptr;
     ctx->d_loose_geom = nullptr;
+    ctx->d_loose_lean = nullptr;
     ctx->d_bvh_nodes = nullptr;
     ctx->d_bvh_leaves = nullptr;
     ctx->n_bvh = ctx->n_loose = 0;
@@ -300,6 +303,7 @@ int build_hierarchy(pt_ctx *ctx, const pt_surface *surfaces, int n_surfaces)
     ctx->d_bvh_leaves = reinterpret_cast<float *>(ctx->d_bvh_nodes + (size_t)n * BVH_NODE_QUADS);
     if ((rc = dev_alloc(ctx, &ctx->d_loose, std::max<size_t>(loose.size(), 1)))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->d_loose_geom, std::max<size_t>(loose.size(), 1) * GEOM_STRIDE))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_loose_lean, std::max<size_t>(loose.size(), 1) * LEAN_STRIDE))) return rc;
     Scratch<int> d_loose_runs;
     std::vector<int> loose_runs(loose.size());
     if (!loose.empty()) {
@@ -311,6 +315,9 @@ int build_hierarchy(pt_ctx *ctx, const pt_surface *surfaces, int n_surfaces)
         if ((rc = upload(ctx, d_loose_runs, loose_runs.data(), loose_runs.size()))) return rc;
         hipLaunchKernelGGL(k_bvh_gather_loose, dim3((unsigned)((loose.size() + 255) / 256)), dim3(256), 0, ctx->stream,
                            ctx->d_geom, ctx->d_loose, d_loose_runs.p, (int)loose.size(), ctx->d_loose_geom);
+        HIP_TRY(ctx, hipGetLastError());
+        hipLaunchKernelGGL(k_lean_records, dim3(blocks_for((long long)loose.size())), dim3(BLOCK), 0, ctx->stream,
+                           ctx->d_loose_geom, (int)loose.size(), ctx->d_loose_lean);
         HIP_TRY(ctx, hipGetLastError());
     }
 
@@ -361,6 +368,7 @@ SceneView scene_view(const pt_ctx *ctx)
     v.n_scan = ctx->n_bvh > 0 ? ctx->n_loose : ctx->n_surfaces;
     v.loose = ctx->d_loose;
     v.loose_geom = ctx->d_loose_geom;
+    v.loose_lean = ctx->d_loose_lean;
     v.bvh.nodes = ctx->d_bvh_nodes;
     v.bvh.leaves = ctx->d_bvh_leaves;
     v.bvh.n_leaves = ctx->n_bvh;
@@ -759,6 +767,7 @@ void pt_destroy(pt_ctx *ctx)
     if (ctx->d_lean) (void)hipFree(ctx->d_lean);
     if (ctx->d_loose) (void)hipFree(ctx->d_loose);
     if (ctx->d_loose_geom) (void)hipFree(ctx->d_loose_geom);
+    if (ctx->d_loose_lean) (void)hipFree(ctx->d_loose_lean);
     if (ctx->d_bvh_nodes) (void)hipFree(ctx->d_bvh_nodes);      // the leaves live in the same allocation
     if (ctx->d_accum) (void)hipFree(ctx->d_accum);
     if (ctx->h_mapped) (void)hipHostFree(ctx->h_mapped);

@@ -30,6 +30,7 @@ struct SceneView {
     const int *loose;         // with a hierarchy: the n_scan scene indices to scan, ascending
     const float *loose_geom;  // and their geometry records, copied out in that order (a scan of
                               // consecutive records: no look-up of an index before each one)
+    const float *loose_lean;  // and their lean records (the FAST policy's scan)
     BvhView bvh;
     float bg[3];
     int max_depth;            // a path ends after this many segments (1..MAX_DEPTH)
@@ -52,7 +53,9 @@ PT_DEV Hit closest_hit(const SceneView &sc, V3 o, V3 d, float *lds, unsigned lon
         if constexpr (FAST) return closest_intersection_lean<WAVE_SKIP, QUERY>(as_constant(sc.lean), sc.n_scan, o, d);
         else return closest_intersection<FAST, NEED_DIST, WAVE_SKIP>(as_constant(sc.geom), sc.n_scan, o, d, redo_count);
     } else {
-        Hit h = closest_intersection<FAST, true>(as_constant(sc.loose_geom), sc.n_scan, o, d, redo_count);
+        Hit h;
+        if constexpr (FAST) h = closest_intersection_lean<false, QUERY>(as_constant(sc.loose_lean), sc.n_scan, o, d);
+        else h = closest_intersection<FAST, true>(as_constant(sc.loose_geom), sc.n_scan, o, d, redo_count);
         if (h.idx >= 0) h.idx = sc.loose[h.idx];
         if constexpr (BVH_STACK_IN_LDS) {
             closest_in_bvh<FAST>(sc.bvh, sc.geom, sc.n_surfaces, o, d, h,
@@ -651,7 +654,11 @@ k_render_mega_bvh(RenderParams P)
             if (waits && alive) {
                 if (need_path) path_begin(ps, P.cam, it.pixel_key, it.s, it.px, it.py);
                 // the surfaces outside the hierarchy first, then the hierarchy
-                Hit outside = closest_intersection<FAST, true>(as_constant(P.scene.loose_geom), P.scene.n_scan,
+                Hit outside;
+                if constexpr (FAST)
+                    outside = closest_intersection_lean<false>(as_constant(P.scene.loose_lean), P.scene.n_scan, ps.o, ps.d);
+                else
+                    outside = closest_intersection<FAST, true>(as_constant(P.scene.loose_geom), P.scene.n_scan,
                                                                ps.o, ps.d, P.stats + 1);
                 if (outside.idx >= 0) outside.idx = P.scene.loose[outside.idx];
                 if constexpr (!FAST) stack[BVH_STACK] = __builtin_bit_cast(int, outside.t);
