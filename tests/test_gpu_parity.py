@@ -37,6 +37,31 @@ def test_primary_hits_bit_exact_vs_golden_800(ctx, pt, golden, name):
     assert np.array_equal(dist[::8, ::8], g[name + "_dist"])
 
 
+@pytest.mark.parametrize("name", SCENES)
+def test_fast_policy_primary_hits_against_golden_800(ctx, pt, golden, name):
+    """The FAST policy promises statistical agreement only; measured against the bit-exact
+    golden on the same non-jittered camera rays it names the same surface for all but a few
+    silhouette pixels (rays within rounding of an edge), and where it does, the distance agrees
+    to 2e-5 relative on the Cornell boxes and 2e-4 at worst: the reference's own unfused fp32 t
+    carries a rounding error of that size wherever a surface is much larger than the distance to
+    it (walls with edges of 11 units seen from 4 away; a ground triangle 200 across; a sphere of
+    radius 1000), which EXACT reproduces bit for bit and a fused evaluation does not.  (The 1e-5
+    bar for distances is EXACT's.)"""
+    g = golden("primary_hits_800.npz")
+    load(ctx, pt.builtin_scene(name, 800, 800))
+    idx, dist = ctx.primary_hits(pt.NUM_FAST)
+    want = g[name + "_idx"].astype(np.int32)
+    differ = int((idx != want).sum())
+    print("%s: FAST names another surface for %d of %d camera rays" % (name, differ, idx.size))
+    assert differ <= 64                       # 1e-4 of the image
+    same = (idx == want)[::8, ::8] & (want[::8, ::8] >= 0)
+    got, ref = dist[::8, ::8][same].astype(np.float64), g[name + "_dist"][same].astype(np.float64)
+    finite = np.isfinite(ref)
+    worst = float((np.abs(got[finite] - ref[finite]) / ref[finite]).max()) if finite.any() else 0.0
+    print("%s: largest relative difference of a distance %.2e" % (name, worst))
+    assert worst <= (3e-5 if name in ("cornell", "cornell_2", "orange_plane", "red_corner") else 3e-4)
+
+
 def test_reference_known_answers_on_gpu(ctx, pt):
     with open(os.path.join(GOLDEN, "reference_known_answers.json")) as f:
         kat = json.load(f)
