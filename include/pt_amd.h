@@ -47,11 +47,12 @@ extern "C" {
 #define PT_NUM_FAST        0x10  /* FMA + hardware rcp/rsq/sin/cos */
 
 /* pt_set_accel modes */
-#define PT_ACCEL_AUTO 0   /* hierarchy when the scene has 16 small triangles or more (and no more than
-                             it can hold: 2^25; beyond that, the scan) */
+#define PT_ACCEL_AUTO 0   /* hierarchy when the scene has 16 small triangles or more, eight small spheres
+                             counting as one triangle (and no more leaves than it can hold: 2^25;
+                             beyond that, the scan) */
 #define PT_ACCEL_NONE 1   /* always the reference's linear scan over every surface */
-#define PT_ACCEL_BVH  2   /* hierarchy whenever the scene has two small triangles or more;
-                             PT_E_LIMIT beyond 2^25 of them */
+#define PT_ACCEL_BVH  2   /* hierarchy whenever the scene has two small triangles or more (small spheres
+                             join them from 32 of them on); PT_E_LIMIT beyond 2^25 leaves */
 #define PT_ACCEL_LDS_TILES 3  /* linear scan with the records staged through LDS in tiles shared by a
                                  workgroup (pt_render's megakernel, pt_primary_hits, pt_intersect_rays):
                                  the layout kept to be measured against PT_ACCEL_NONE's scan through
@@ -108,7 +109,7 @@ typedef struct pt_counters {
                                   else PT_ACCEL_NONE */
     uint32_t reserved;
     uint64_t node_steps;       /* PT_MODE_COUNT_STEPS: hierarchy node records opened (two box tests each) */
-    uint64_t leaf_steps;       /* PT_MODE_COUNT_STEPS: hierarchy leaf triangles tested */
+    uint64_t leaf_steps;       /* PT_MODE_COUNT_STEPS: hierarchy leaves (triangles, spheres) tested */
 } pt_counters;
 
 typedef struct pt_ctx pt_ctx;
@@ -142,14 +143,18 @@ int pt_set_scene(pt_ctx *ctx, const pt_surface *surfaces, int32_t n_surfaces,
 /* Chooses how the closest hit is searched; rebuilds for the current scene.
  * The reference scans every surface for every segment (src/main.cpp:58-66;
  * an "octree" is a to-do note, src/main.cpp:75).  The hierarchy, built on the
- * GPU over the scene's small triangles, returns the same surface, t and
- * distance as the scan, ties included: candidates are evaluated in the
+ * GPU over the scene's small triangles and spheres, returns the same surface,
+ * t and distance as the scan, ties included: candidates are evaluated in the
  * reference's arithmetic, and the boxes are padded for what that arithmetic
  * accepts outside a triangle (its 1e-5 tolerances, and the error of its u and
  * v for rays nearly parallel to a triangle, where its determinant is just
- * above the 1e-5 cut-off).  Checked on random scenes against the scan, rays
- * aimed at edges, vertices and along triangle planes included
- * (tools/soak_parity.py). */
+ * above the 1e-5 cut-off) and grown, ray by ray, by what it accepts outside a
+ * sphere (the rounding of its d2, which grows with the ray's distance).
+ * Sphere::intersects takes the direction for a unit vector; a ray whose
+ * direction is not one to within 1e-3 (pt_intersect_rays only) is answered by
+ * the scan whenever the hierarchy holds spheres.  Checked on random scenes
+ * against the scan, rays aimed at edges and vertices, along triangle planes
+ * and along sphere silhouettes included (tools/soak_parity.py). */
 int pt_set_accel(pt_ctx *ctx, int accel);
 
 /* Ends every path of later renders after max_segments closest-hit queries

@@ -94,6 +94,7 @@ struct pt_ctx {
     int max_depth = PT_MAX_DEPTH;    // segments per path at most (pt_set_max_depth)
     int n_bvh = 0, n_loose = 0;
     float bvh_ray_reach = 0.0f;
+    float bvh_sphere_term = 0.0f, bvh_sphere_reach = 0.0f;     // BvhView
     int *d_loose = nullptr;
     float *d_loose_geom = nullptr;
     float *d_loose_lean = nullptr;      // the FAST policy's records of the same surfaces, same order
@@ -201,6 +202,8 @@ int check_ready(pt_ctx *ctx, bool need_camera)
 // 0.65 / 0.61, 0.21 / 0.24; 18 + 7: 4.67 / 3.21, 0.84 / 0.63, 0.29 / 0.25; 242 + 7: 26.2 / 3.7,
 // 4.25 / 0.87, 1.42 / 0.34.
 constexpr int BVH_AUTO_MIN_TRIANGLES = 16;
+constexpr int BVH_AUTO_SPHERES_PER_TRIANGLE = 8;
+constexpr int BVH_MIN_SPHERES_INSIDE = 32;
 // Measured, 800 x 800: 80 spheres 46.2 -> 32.2 ms and 249 small triangles 45.0 -> 30.3 ms with the
 // early-outs; 15 triangles 16.4 -> 16.8 ms and the three large spheres of cornell_2 -10 % (hence off).
 constexpr int WAVE_SKIP_MIN_SPHERES = 16, WAVE_SKIP_MIN_TRIANGLES = 32;
@@ -218,46 +221,76 @@ int build_hierarchy(pt_ctx *ctx, const pt_surface *surfaces, int n_surfaces)
     ctx->d_bvh_leaves = nullptr;
     ctx->n_bvh = ctx->n_loose = 0;
     if (ctx->accel == PT_ACCEL_NONE || ctx->accel == PT_ACCEL_LDS_TILES) return PT_OK;
-    if (ctx->accel == PT_ACCEL_AUTO && ctx->n_tri < BVH_AUTO_MIN_TRIANGLES) return PT_OK;
+    if (ctx->accel == PT_ACCEL_AUTO && ctx->n_tri + ctx->n_sph < BVH_AUTO_MIN_TRIANGLES) return PT_OK;
 
-    // bounds of the triangle centroids; a triangle much larger than that spread stays outside
+    // bounds of the surfaces' centres (triangle centroids, sphere centres); a surface much larger
+    // than that spread stays outside
+    auto centre = [&](const pt_surface &s, int k) {
+        return s.kind == PT_TRIANGLE ? (s.a[k] + s.b[k] + s.c[k]) / 3.0f : s.a[k];
+    };
     float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = 0; i < n_surfaces; i++) {
-        if (surfaces[i].kind != PT_TRIANGLE) continue;
+    for (int i = 0; i < n_surfaces; i++)
         for (int k = 0; k < 3; k++) {
-            const float c = (surfaces[i].a[k] + surfaces[i].b[k] + surfaces[i].c[k]) / 3.0f;
+            const float c = centre(surfaces[i], k);
+            if (!std::isfinite(c)) continue;
             cmin[k] = std::min(cmin[k], c);
             cmax[k] = std::max(cmax[k], c);
         }
-    }
     const float spread = (cmax[0] - cmin[0]) + (cmax[1] - cmin[1]) + (cmax[2] - cmin[2]);
     std::vector<int> loose, inside;
+    float radius_min = INFINITY, sphere_reach = 0.0f;
+    // spheres join only where there are many: with any of them inside, every box test of every ray
+    // carries the ray's own padding (box_entry_padded), which a few spheres scanned beside the
+    // hierarchy do not cost
+    int small_spheres = 0;
+    auto sphere_fits = [&](const pt_surface &s) {
+        const float r = s.b[0], reach = std::fabs(s.a[0]) + std::fabs(s.a[1]) + std::fabs(s.a[2]);
+        return std::isfinite(r) && std::isfinite(reach) && r > 0.0f && 6.0f * r <= 0.25f * spread &&
+               r >= 1e-3f * spread && r * r >= 1e-30f && reach <= 1e15f;
+    };
+    for (int i = 0; i < n_surfaces; i++) small_spheres += surfaces[i].kind == PT_SPHERE && sphere_fits(surfaces[i]);
+    const bool spheres_inside = small_spheres >= BVH_MIN_SPHERES_INSIDE;
     for (int i = 0; i < n_surfaces; i++) {
-        bool in = surfaces[i].kind == PT_TRIANGLE;
-        if (in) {
+        const pt_surface &s = surfaces[i];
+        bool in = false;
+        if (s.kind == PT_TRIANGLE) {
             float size = 0;
             for (int k = 0; k < 3; k++) {
-                const float lo = std::min({surfaces[i].a[k], surfaces[i].b[k], surfaces[i].c[k]});
-                const float hi = std::max({surfaces[i].a[k], surfaces[i].b[k], surfaces[i].c[k]});
+                const float lo = std::min({s.a[k], s.b[k], s.c[k]});
+                const float hi = std::max({s.a[k], s.b[k], s.c[k]});
                 size += hi - lo;
             }
-            in = std::isfinite(size) && size <= 0.1f * spread && !extreme_triangle(surfaces[i]);
+            in = std::isfinite(size) && size <= 0.1f * spread && !extreme_triangle(s);
+        } else {
+            // a sphere: its box is 2 r a side; not so small that the allowance every ray makes for
+            // the reference's rounding (BVH_SPHERE_ROUNDING / smallest radius) grows large
+            in = spheres_inside && sphere_fits(s);
+            if (in) {
+                radius_min = std::min(radius_min, s.b[0]);
+                sphere_reach = std::max(sphere_reach, std::fabs(s.a[0]) + std::fabs(s.a[1]) + std::fabs(s.a[2]));
+            }
         }
         (in ? inside : loose).push_back(i);
     }
     const int n = (int)inside.size();
-    if (n < 2 || (ctx->accel == PT_ACCEL_AUTO && n < BVH_AUTO_MIN_TRIANGLES)) return PT_OK;
+    // (a sphere the scan rejects after a third of its test, and whole waves skip it together: the
+    // hierarchy pays from some 130 small spheres on, against 16 small triangles)
+    int n_in_spheres = 0;
+    for (int i : inside) n_in_spheres += surfaces[i].kind == PT_SPHERE;
+    const int weight = (n - n_in_spheres) + n_in_spheres / BVH_AUTO_SPHERES_PER_TRIANGLE;
+    if (n < 2 || (ctx->accel == PT_ACCEL_AUTO && weight < BVH_AUTO_MIN_TRIANGLES)) return PT_OK;
     if (n > BVH_MAX_LEAVES) {
         if (ctx->accel == PT_ACCEL_AUTO) return PT_OK;           // the scan has no such limit
-        return fail(ctx, PT_E_LIMIT, "%d triangles exceed the hierarchy's maximum of %d", n, BVH_MAX_LEAVES);
+        return fail(ctx, PT_E_LIMIT, "%d surfaces exceed the hierarchy's maximum of %d", n, BVH_MAX_LEAVES);
     }
 
-    // centroid bounds of the triangles that go in, for the Morton grid
+    // bounds of the box centres of the surfaces that go in, for the Morton grid
     for (int k = 0; k < 3; k++) { cmin[k] = INFINITY; cmax[k] = -INFINITY; }
     for (int i : inside)
         for (int k = 0; k < 3; k++) {
-            const float lo = std::min({surfaces[i].a[k], surfaces[i].b[k], surfaces[i].c[k]});
-            const float hi = std::max({surfaces[i].a[k], surfaces[i].b[k], surfaces[i].c[k]});
+            const pt_surface &s = surfaces[i];
+            const float lo = s.kind == PT_TRIANGLE ? std::min({s.a[k], s.b[k], s.c[k]}) : s.a[k];
+            const float hi = s.kind == PT_TRIANGLE ? std::max({s.a[k], s.b[k], s.c[k]}) : s.a[k];
             cmin[k] = std::min(cmin[k], 0.5f * (lo + hi));
             cmax[k] = std::max(cmax[k], 0.5f * (lo + hi));
         }
@@ -355,6 +388,8 @@ int build_hierarchy(pt_ctx *ctx, const pt_surface *surfaces, int n_surfaces)
     ctx->n_bvh = n;
     ctx->n_loose = (int)loose.size();
     ctx->bvh_ray_reach = ray_reach;
+    ctx->bvh_sphere_term = std::isfinite(radius_min) ? 1.0f / radius_min : 0.0f;
+    ctx->bvh_sphere_reach = sphere_reach;
     return PT_OK;
 }
 
@@ -373,6 +408,8 @@ SceneView scene_view(const pt_ctx *ctx)
     v.bvh.leaves = ctx->d_bvh_leaves;
     v.bvh.n_leaves = ctx->n_bvh;
     v.bvh.ray_reach = ctx->bvh_ray_reach;
+    v.bvh.sphere_term = ctx->bvh_sphere_term;
+    v.bvh.sphere_reach = ctx->bvh_sphere_reach;
     memcpy(v.bg, ctx->bg, sizeof v.bg);
     v.max_depth = ctx->max_depth;
     return v;
@@ -446,9 +483,11 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
     // field at 1 spp 2949 -> 2733, 80 spheres 1113 -> 1089; 356x200 at 1 spp 259 -> 124.
     const int blocks_wanted = std::max(1, (int)std::lround(0.9 + std::log2(std::max(samples, 1.0) / 2e5)));
     if constexpr (KIND == SCENE_BVH) {
-        kernel = &k_render_mega_bvh<FAST>;
-        if (blocks_wanted >= 8) kernel = &k_render_mega_bvh<FAST, 7>;       // from 2e7 samples on
-        if (count_steps) kernel = &k_render_mega_bvh<FAST, 6, true>;
+        const bool spheres = ctx->bvh_sphere_term > 0.0f;                   // spheres among the leaves
+        kernel = spheres ? &k_render_mega_bvh<FAST, 6, false, true> : &k_render_mega_bvh<FAST>;
+        if (blocks_wanted >= 8)                                             // from 2e7 samples on
+            kernel = spheres ? &k_render_mega_bvh<FAST, 7, false, true> : &k_render_mega_bvh<FAST, 7>;
+        if (count_steps) kernel = spheres ? &k_render_mega_bvh<FAST, 6, true, true> : &k_render_mega_bvh<FAST, 6, true>;
     }
     int blocks_per_cu = 0;
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, BLOCK, lds_bytes));

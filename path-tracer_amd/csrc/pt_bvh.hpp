@@ -1,4 +1,4 @@
-// Bounding-volume hierarchy over a scene's small triangles, built on the GPU
+// Bounding-volume hierarchy over a scene's small triangles and spheres, built on the GPU
 // (Morton codes, radix sort, Karras' parallel hierarchy, bottom-up refit) and
 // traversed per lane with a private stack.  The reference has no acceleration
 // structure (an "octree" is a to-do note, src/main.cpp:75); this one returns
@@ -19,8 +19,24 @@ constexpr int BVH_NODE_QUADS = 4;
 constexpr int BVH_MAX_LEAVES = 1 << 25;          // nodes + leaves, 64 bytes each, within 4 GiB
 constexpr float BVH_ORIGIN_ROUNDING = 8e-6f;     // of |o|: some 60 ulps
 constexpr float BVH_GRAZING = 0.05f;             // some 8 eps / 1e-5
-// A leaf is one triangle: its geometry record (GEOM_STRIDE floats) with the
-// surface's index in scene order in element 3 (where a geometry record keeps the kind).
+// A leaf is one surface: its geometry record (GEOM_STRIDE floats) with the surface's index in
+// scene order in element 3 (where a geometry record keeps the kind) and the kind in element 11.
+constexpr int BVH_LEAF_KIND = 11;
+// Spheres (src/surface.hpp:91-112).  The reference forms d2 = L.L - tca^2 in fp32 and accepts
+// d2 <= radius2, so a hit it reports can lie outside the sphere by the rounding of d2 - some
+// 8 eps |L|^2 in d2, i.e. 4 eps |L|^2 / radius + 2 eps |L| in distance from the centre, L = centre -
+// origin - which grows with the ray's distance, not with the sphere.  The boxes are not padded
+// for it; every ray widens its box tests instead (BvhCursor::slack) by
+// BVH_SPHERE_ROUNDING * (|o| + |c|max)^2 / radius_min, twice (both ends of an interval move) and
+// with a factor of four in hand.
+// The reference's test also takes the direction for a unit vector: with |d|^2 = 1 + e it forms
+// d2 = L.L - (1 + e) tca^2, and what it accepts is the sphere only up to e |L|^2 / (2 radius) - for
+// the directions a render produces (e of some 1e-6: a normalisation, the hardware sine) one more
+// term of the same kind, which the ray adds from its own |d|; a ray with |e| above
+// BVH_SPHERE_UNIT_TOLERANCE (only a caller's own rays: pt_intersect_rays) asks for something no box
+// bounds, and is answered by the scan of every surface.
+constexpr float BVH_SPHERE_ROUNDING = 4e-6f;
+constexpr float BVH_SPHERE_UNIT_TOLERANCE = 1e-3f;
 constexpr int BVH_STACK = 64;        // deepest possible tree: one level per key bit
 // Where the per-lane traversal stacks live.  In LDS they cost 64 KiB per
 // workgroup, which leaves two workgroups per CU; in private memory they cost
@@ -39,6 +55,8 @@ struct BvhView {
     const float *leaves;     // n_leaves * GEOM_STRIDE, directly behind the nodes' n_leaves records
     int n_leaves;            // 0: the scene has no hierarchy
     float ray_reach;         // the boxes allow for ray origins with |x| + |y| + |z| up to this
+    float sphere_term;       // 0: no spheres in the hierarchy; else 1 / smallest radius among them
+    float sphere_reach;      // largest |x| + |y| + |z| of a sphere centre in the hierarchy
 };
 
 // ---------------------------------------------------------------- build
@@ -76,6 +94,23 @@ k_bvh_prepare(const float *geom, const int *tri_idx, int n, float3 cmin, float3 
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     const float *g = geom + (size_t)tri_idx[j] * GEOM_STRIDE;
+    if (__float_as_int(g[3]) == GEOM_SPHERE) {
+        // the sphere's own box, with room for the rounding of the radius (the record holds its
+        // square) and of hit points; what the reference's rounding adds is the rays' business
+        const V3 c = v3(g[0], g[1], g[2]);
+        const float r = sqrtf(g[4]);
+        const float reach = fmaxf(fabsf(c.x), fmaxf(fabsf(c.y), fabsf(c.z))) + r;
+        const float pad = 1e-5f * (1.0f + reach) + 1e-5f * r + BVH_ORIGIN_ROUNDING * ray_reach;
+        box_min[j] = make_float4(c.x - r - pad, c.y - r - pad, c.z - r - pad, 0.0f);
+        box_max[j] = make_float4(c.x + r + pad, c.y + r + pad, c.z + r + pad, 0.0f);
+        constexpr float CELLS_S = (float)(1 << BVH_CODE_BITS);
+        const uint32_t sx = (uint32_t)fminf(fmaxf((c.x - cmin.x) * cinv.x * CELLS_S, 0.0f), CELLS_S - 1.0f);
+        const uint32_t sy = (uint32_t)fminf(fmaxf((c.y - cmin.y) * cinv.y * CELLS_S, 0.0f), CELLS_S - 1.0f);
+        const uint32_t sz = (uint32_t)fminf(fmaxf((c.z - cmin.z) * cinv.z * CELLS_S, 0.0f), CELLS_S - 1.0f);
+        const unsigned long long code_s = (spread_bits(sx) << 2) | (spread_bits(sy) << 1) | spread_bits(sz);
+        keys[j] = (code_s << BVH_INDEX_BITS) | (unsigned long long)j;
+        return;
+    }
     const V3 v0 = v3(g[0], g[1], g[2]);
     const V3 v1 = v0 + v3(g[4], g[5], g[6]), v2 = v0 + v3(g[8], g[9], g[10]);
     V3 lo = v3(fminf(v0.x, fminf(v1.x, v2.x)), fminf(v0.y, fminf(v1.y, v2.y)), fminf(v0.z, fminf(v1.z, v2.z)));
@@ -201,9 +236,10 @@ k_bvh_leaves(const unsigned long long *keys, int n, const float *geom, const int
     const int i = tri_idx[bvh_key_index(keys[k])];
     const float4 *src = reinterpret_cast<const float4 *>(geom + (size_t)i * GEOM_STRIDE);
     float4 *dst = reinterpret_cast<float4 *>(leaves + (size_t)k * GEOM_STRIDE);
-    float4 a = src[0];
+    float4 a = src[0], c = src[2];
+    c.w = a.w;                       // the kind moves to BVH_LEAF_KIND
     a.w = __int_as_float(i);
-    dst[0] = a; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+    dst[0] = a; dst[1] = src[1]; dst[2] = c; dst[3] = src[3];
 }
 
 // The geometry records of the surfaces outside the hierarchy, copied out in scan order,
@@ -237,11 +273,30 @@ PT_DEV float box_entry(float4 bmin, float4 bmax, V3 o, V3 inv, float t_far, floa
     return t_in <= t_out + slack ? t_in : -1.0f;
 }
 
+// The same against the box grown by `pad` on every side (a distance, the ray's own: hierarchies
+// that hold spheres, BVH_SPHERE_ROUNDING): every slab crossing moves by pad / |d_k|; an axis the
+// ray is parallel to (1/d_k infinite) keeps its crossings, which are infinite already.
+PT_DEV float box_entry_padded(float4 bmin, float4 bmax, V3 o, V3 inv, float t_far, float pad)
+{
+    const float INF = __builtin_inff();
+    const float ix = __builtin_fabsf(inv.x), iy = __builtin_fabsf(inv.y), iz = __builtin_fabsf(inv.z);
+    const float px = ix < INF ? pad * ix : 0.0f, py = iy < INF ? pad * iy : 0.0f, pz = iz < INF ? pad * iz : 0.0f;
+    const float x1 = (bmin.x - o.x) * inv.x, x2 = (bmax.x - o.x) * inv.x;
+    const float y1 = (bmin.y - o.y) * inv.y, y2 = (bmax.y - o.y) * inv.y;
+    const float z1 = (bmin.z - o.z) * inv.z, z2 = (bmax.z - o.z) * inv.z;
+    const float t_in = fmaxf(fmaxf(fminf(x1, x2) - px, fminf(y1, y2) - py), fmaxf(fminf(z1, z2) - pz, 0.0f));
+    const float t_out = fminf(fminf(fmaxf(x1, x2) + px, fmaxf(y1, y2) + py), fminf(fmaxf(z1, z2) + pz, t_far));
+    return t_in <= t_out ? t_in : -1.0f;
+}
+
 // A lane's traversal in progress.
 struct BvhCursor {
     V3 inv;              // 1/d per component
-    float len_d, inv_len;
-    float slack;         // in units of the ray parameter: what the origin's rounding can move a slab crossing
+    float len_d, inv_len;   // |d|; ray parameter per unit of distance (an upper bound of it: bvh_begin)
+    float slack;         // what the box tests allow for this ray beyond the boxes' own padding: in a hierarchy
+                         // of triangles a ray parameter (what the origin's rounding can move a slab crossing,
+                         // rays from beyond ray_reach only); in one that holds spheres a distance by which
+                         // every box is grown (bvh_begin)
     int node;            // >= 0: internal node to open; < 0: leaf ~node to test
     int sp;              // entries on the stack
     int top;             // the newest entry, kept in a register: a pop then costs no memory
@@ -277,12 +332,16 @@ PT_DEV BvhBest bvh_best_from(const Hit &outside)
 // normal range, a hit outside the hierarchy (`outside`) whose distance is not a
 // number, and (in bvh_test_leaf) a leaf hit whose distance is not finite all set
 // c.direct, and bvh_finish then scans every surface in scene order instead.
-template <bool FAST>
+template <bool FAST, bool SPHERES = true>
 PT_DEV void bvh_begin(BvhCursor &c, const BvhView &bvh, V3 o, V3 d, const Hit &outside)
 {
     c.inv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
     c.len_d = __builtin_amdgcn_sqrtf(Num<FAST>::dot(d, d));
     c.inv_len = __builtin_amdgcn_rcpf(c.len_d);
+    // A triangle's distance is |t d| (src/surface.hpp:70), a sphere's is t itself whatever the
+    // direction's length (surface.hpp:111): with spheres in the hierarchy a box entered at
+    // parameter t may hold a hit at distance t or t |d|, and only the smaller can be used to prune.
+    if (SPHERES && bvh.sphere_term > 0.0f) c.inv_len = fmaxf(c.inv_len, 1.0f);
     c.sp = 0;
     c.top = 0;
     c.node = bvh.n_leaves > 1 ? 0 : ~0;
@@ -298,7 +357,16 @@ PT_DEV void bvh_begin(BvhCursor &c, const BvhView &bvh, V3 o, V3 d, const Hit &o
         // moves by the rounding of o over |d_k|; an axis the ray is parallel to
         // (1/d_k infinite) has no crossing to move.  (One slack for all axes: such
         // rays are slow, not wrong.)
-        if (reach > bvh.ray_reach) {
+        const bool far_out = reach > bvh.ray_reach;
+        if (SPHERES && bvh.sphere_term > 0.0f) {            // the same for every ray of a launch
+            // spheres in the hierarchy: every box grows by what the reference's rounding can add to
+            // a sphere for this ray (BVH_SPHERE_ROUNDING)
+            const float far = reach + bvh.sphere_reach;
+            const float off_unit = __builtin_fabsf(__builtin_fmaf(c.len_d, c.len_d, -1.0f));
+            c.direct = c.direct | !(off_unit <= BVH_SPHERE_UNIT_TOLERANCE);
+            c.slack = (far_out ? BVH_ORIGIN_ROUNDING * reach : 0.0f) +
+                      (BVH_SPHERE_ROUNDING + 2.0f * off_unit) * bvh.sphere_term * far * far;
+        } else if (far_out) {
             const float ix = __builtin_fabsf(c.inv.x), iy = __builtin_fabsf(c.inv.y), iz = __builtin_fabsf(c.inv.z);
             const float steepest = fmaxf(fmaxf(ix < INF ? ix : 0.0f, iy < INF ? iy : 0.0f), iz < INF ? iz : 0.0f);
             c.slack = BVH_ORIGIN_ROUNDING * reach * steepest;
@@ -322,19 +390,43 @@ PT_DEV bool bvh_leaf_exact(const TriDets &q, V3 d, float &t, float &dist)
     return ok;
 }
 
-PT_DEV TriDets bvh_leaf_dets(const BvhView &bvh, int leaf, V3 o, V3 d, int &scene_index)
+PT_DEV TriDets bvh_leaf_dets(float4 g0, float4 g1, float4 g2, V3 o, V3 d)
+{
+    return triangle_dets_v<false>(v3(g0.x, g0.y, g0.z), v3(g1.x, g1.y, g1.z), g1.w, v3(g2.x, g2.y, g2.z), o, -d);
+}
+
+// The exact evaluation of a leaf sphere (centre g0.xyz, radius2 g1.x), as Sphere::intersects
+// does it (src/surface.hpp:91-112).
+PT_DEV bool bvh_sphere_exact(float4 g0, float4 g1, V3 o, V3 d, float &t, float &dist)
+{
+    float tca, arg;
+    bool ok = sphere_pre_v<false>(v3(g0.x, g0.y, g0.z), g1.x, o, d, tca, arg);
+    const float thc = __builtin_sqrtf(arg);
+    t = tca - thc;
+    if (t <= EPS_F) {
+        t = tca + thc;
+        ok = ok & !(t <= EPS_F);
+    }
+    dist = t;
+    return ok;
+}
+
+// Leaf `leaf` (position in Morton order) evaluated exactly, whichever kind it has.
+template <bool SPHERES = true>
+PT_DEV bool bvh_leaf_exact_any(const BvhView &bvh, int leaf, V3 o, V3 d, int &scene_index, float &t, float &dist)
 {
     const float4 *g = reinterpret_cast<const float4 *>(bvh.leaves + (size_t)leaf * GEOM_STRIDE);
     const float4 g0 = g[0], g1 = g[1], g2 = g[2];
     scene_index = __float_as_int(g0.w);
-    return triangle_dets_v<false>(v3(g0.x, g0.y, g0.z), v3(g1.x, g1.y, g1.z), g1.w, v3(g2.x, g2.y, g2.z), o, -d);
+    if (SPHERES && __float_as_int(g2.w) == GEOM_SPHERE) return bvh_sphere_exact(g0, g1, o, d, t, dist);
+    return bvh_leaf_exact(bvh_leaf_dets(g0, g1, g2, o, d), d, t, dist);
 }
 
 // After the traversal: the closest hit overall, with the reference's t and
 // distance (idx < 0: none).  geom, n_surfaces: every surface's geometry record.
 // outside_t: the ray parameter of the hit outside the hierarchy the traversal
 // began with (bvh_best_from), which is the answer when no leaf came closer.
-template <bool FAST>
+template <bool FAST, bool SPHERES = true>
 PT_DEV Hit bvh_finish(const BvhCursor &c, const BvhView &bvh, const float *geom, int n_surfaces, V3 o, V3 d,
                       const BvhBest &best, float outside_t)
 {
@@ -349,8 +441,7 @@ PT_DEV Hit bvh_finish(const BvhCursor &c, const BvhView &bvh, const float *geom,
             // a surface outside the hierarchy won: the scan that found it has its exact t and distance
             h = {best.ref, outside_t, best.lo};
         } else {
-            const TriDets q = bvh_leaf_dets(bvh, ~best.ref, o, d, h.idx);
-            bvh_leaf_exact(q, d, h.t, h.dist);
+            bvh_leaf_exact_any<SPHERES>(bvh, ~best.ref, o, d, h.idx, h.t, h.dist);
         }
         return h;
     }
@@ -358,14 +449,20 @@ PT_DEV Hit bvh_finish(const BvhCursor &c, const BvhView &bvh, const float *geom,
 
 // Opens an internal node (its four quads): true when the traversal descends
 // into a child (c.node), false when neither child can hold a closer hit.
-PT_DEV bool bvh_open_node(BvhCursor &c, float4 q0, float4 q1, float4 q2, float4 q3, V3 o, float bound,
+PT_DEV bool bvh_open_node(BvhCursor &c, bool padded, float4 q0, float4 q1, float4 q2, float4 q3, V3 o, float bound,
                           int *stack, int stride)
 {
     // nothing beyond `bound`, an upper bound of the best distance, can win; the margin
     // covers the rounding of t * |d|
     const float t_far = bound * c.inv_len * (1.0f + 1e-5f);
-    const float tl = box_entry(q0, q1, o, c.inv, t_far, c.slack);
-    const float tr = box_entry(q2, q3, o, c.inv, t_far, c.slack);
+    float tl, tr;
+    if (padded) {                                   // wave-uniform: the hierarchy holds spheres
+        tl = box_entry_padded(q0, q1, o, c.inv, t_far, c.slack);
+        tr = box_entry_padded(q2, q3, o, c.inv, t_far, c.slack);
+    } else {
+        tl = box_entry(q0, q1, o, c.inv, t_far, c.slack);
+        tr = box_entry(q2, q3, o, c.inv, t_far, c.slack);
+    }
     const int left = __float_as_int(q0.w), right = __float_as_int(q1.w);
     if (tl >= 0.0f && tr >= 0.0f) {                 // both: nearer first
         const bool left_first = tl <= tr;
@@ -381,28 +478,66 @@ PT_DEV bool bvh_open_node(BvhCursor &c, float4 q0, float4 q1, float4 q2, float4 
 }
 
 // Tests leaf ~c.node (the first three quads of its record) against the best candidate so far.
-template <bool FAST>
+// SPHERES: the hierarchy may hold spheres (false: the render kernel compiled for hierarchies of
+// triangles only, without the sphere's code and the padded box test in its loop - 8 % faster
+// on the million-triangle field than the general one).
+template <bool FAST, bool SPHERES = true>
 PT_DEV void bvh_test_leaf(BvhCursor &c, const BvhView &bvh, float4 g0, float4 g1, float4 g2, V3 o, V3 d, BvhBest &best)
 {
-    const V3 nd = -d;
     const int idx = __float_as_int(g0.w);
-    const TriDets q = triangle_dets_v<FAST>(v3(g0.x, g0.y, g0.z), v3(g1.x, g1.y, g1.z), g1.w,
-                                            v3(g2.x, g2.y, g2.z), o, nd);
-    const float rinv = __builtin_amdgcn_rcpf(q.det_a);
-    const float u = q.du * rinv, v = q.dv * rinv, t = q.dt * rinv;
-    const float s = u + v;
-    const bool det_bad = __builtin_fabsf(q.det_a) <= EPS_F;
-    const float dist = t * c.len_d;
-    if constexpr (FAST) {
-        // (t by a positive compare: a NaN is no hit)
-        const bool acc = !(det_bad | (u < -EPS_F) | (u >= 1.0f) | (v < -EPS_F) | (s >= 1.0f)) & (t > EPS_F);
-        if (acc & (dist < best.lo)) best = {idx, dist, t};
+    const bool is_sphere = SPHERES && __float_as_int(g2.w) == GEOM_SPHERE;
+    // the same bands as the scan's filter (scan_surface): rej = surely no hit, acc = surely a hit,
+    // [c_lo, c_hi] brackets the distance the reference computes (FAST: c_lo = the distance, c_hi = t)
+    bool rej, acc;
+    float c_lo, c_hi;
+    if (is_sphere) {
+        float tca, d2, arg;
+        sphere_pre_terms<FAST>(v3(g0.x, g0.y, g0.z), g1.x, o, d, tca, d2, arg);
+        const bool pre_ok = !(tca < 0.0f) & !(d2 > g1.x);                       // surface.hpp:94, :98
+        const float thc = __builtin_amdgcn_sqrtf(arg);
+        const float t1 = tca - thc, t2 = tca + thc;
+        if constexpr (FAST) {
+            const float t = !(t1 <= EPS_F) ? t1 : t2;
+            acc = pre_ok & (t > EPS_F);
+            rej = !acc;
+            c_lo = c_hi = t;
+        } else {
+            const float e1 = SPH_DIST_ERR * (thc + __builtin_fabsf(t1)), e2 = SPH_DIST_ERR * (thc + __builtin_fabsf(t2));
+            const float lo1 = t1 - e1, hi1 = t1 + e1, lo2 = t2 - e2, hi2 = t2 + e2;
+            const bool near_ok = lo1 > BAND_T_ACC, near_bad = hi1 < BAND_T_REJ;
+            const bool far_ok = lo2 > BAND_T_ACC, far_bad = hi2 < BAND_T_REJ;
+            acc = pre_ok & (near_ok | (near_bad & far_ok));
+            rej = !pre_ok | (near_bad & far_bad);
+            // the bracket also serves a leaf that is neither accepted nor rejected yet: the near
+            // root unless it is surely out, the far root unless the near one is surely in
+            c_lo = near_bad ? lo2 : lo1;
+            c_hi = near_ok ? hi1 : hi2;
+        }
     } else {
-        // the same bands as the scan's filter (scan_surface)
-        const float low_uv = __builtin_fminf(u, v);
-        const bool rej = det_bad | (low_uv < BAND_LO_REJ) | (__builtin_fmaxf(u, s) > BAND_ONE_REJ) | (t < BAND_T_REJ);
-        const bool acc = !det_bad & (low_uv > BAND_LO_ACC) & (u < BAND_ONE_ACC) & (s < BAND_ONE_ACC) & (t > BAND_T_ACC);
-        const float c_lo = dist * (1.0f - TRI_DIST_ERR), c_hi = dist * (1.0f + TRI_DIST_ERR);
+        const TriDets q = triangle_dets_v<FAST>(v3(g0.x, g0.y, g0.z), v3(g1.x, g1.y, g1.z), g1.w,
+                                                v3(g2.x, g2.y, g2.z), o, -d);
+        const float rinv = __builtin_amdgcn_rcpf(q.det_a);
+        const float u = q.du * rinv, v = q.dv * rinv, t = q.dt * rinv;
+        const float s = u + v;
+        const bool det_bad = __builtin_fabsf(q.det_a) <= EPS_F;
+        const float dist = t * c.len_d;
+        if constexpr (FAST) {
+            // (t by a positive compare: a NaN is no hit)
+            acc = !(det_bad | (u < -EPS_F) | (u >= 1.0f) | (v < -EPS_F) | (s >= 1.0f)) & (t > EPS_F);
+            rej = !acc;
+            c_lo = dist;
+            c_hi = t;
+        } else {
+            const float low_uv = __builtin_fminf(u, v);
+            rej = det_bad | (low_uv < BAND_LO_REJ) | (__builtin_fmaxf(u, s) > BAND_ONE_REJ) | (t < BAND_T_REJ);
+            acc = !det_bad & (low_uv > BAND_LO_ACC) & (u < BAND_ONE_ACC) & (s < BAND_ONE_ACC) & (t > BAND_T_ACC);
+            c_lo = dist * (1.0f - TRI_DIST_ERR);
+            c_hi = dist * (1.0f + TRI_DIST_ERR);
+        }
+    }
+    if constexpr (FAST) {
+        if (acc & (c_lo < best.lo)) best = {idx, c_lo, c_hi};
+    } else {
         // surely no hit, or (if a hit at all) surely farther than the best
         if (rej | (c_lo > best.hi)) return;
         if (acc & (c_hi < best.lo)) {               // surely a hit and surely closer
@@ -412,17 +547,15 @@ PT_DEV void bvh_test_leaf(BvhCursor &c, const BvhView &bvh, float4 g0, float4 g1
         // Rare: a value inside a band, or distances too close to tell apart.  Both
         // candidates exactly; equal distances go to the earlier surface in scene order.
         float te, dist_e;
-        const bool ok = bvh_leaf_exact(q, d, te, dist_e);
+        const bool ok = is_sphere ? bvh_sphere_exact(g0, g1, o, d, te, dist_e)
+                                  : bvh_leaf_exact(bvh_leaf_dets(g0, g1, g2, o, d), d, te, dist_e);
         c.direct = c.direct | (ok & !(dist_e < __builtin_inff()));
         if (!ok) return;
         int best_idx = best.ref;
         if (best.ref < 0 && best.ref != BVH_NO_HIT) {
-            const TriDets qb = bvh_leaf_dets(bvh, ~best.ref, o, d, best_idx);
-            if (best.lo != best.hi) {
-                float tb, dist_b;
-                bvh_leaf_exact(qb, d, tb, dist_b);
-                best.lo = best.hi = dist_b;
-            }
+            float tb, dist_b;
+            bvh_leaf_exact_any<SPHERES>(bvh, ~best.ref, o, d, best_idx, tb, dist_b);
+            if (best.lo != best.hi) best.lo = best.hi = dist_b;
         }
         if ((dist_e < best.lo) | ((dist_e == best.lo) & (idx < best_idx) & (best.ref != BVH_NO_HIT)))
             best = {c.node, dist_e, dist_e};
@@ -440,14 +573,15 @@ PT_DEV bool bvh_pop(BvhCursor &c, const int *stack, int stride)
 }
 
 // Advances a traversal by one node or one leaf, given the record c.node names.
-template <bool FAST>
+template <bool FAST, bool SPHERES = true>
 PT_DEV bool bvh_advance(BvhCursor &c, const BvhView &bvh, float4 q0, float4 q1, float4 q2, float4 q3, V3 o, V3 d,
                         BvhBest &best, int *stack, int stride)
 {
     if (c.node >= 0) {
-        if (bvh_open_node(c, q0, q1, q2, q3, o, FAST ? best.lo : best.hi, stack, stride)) return true;
+        if (bvh_open_node(c, SPHERES && !FAST && bvh.sphere_term > 0.0f, q0, q1, q2, q3, o, FAST ? best.lo : best.hi, stack, stride))
+            return true;
     } else {
-        bvh_test_leaf<FAST>(c, bvh, q0, q1, q2, o, d, best);
+        bvh_test_leaf<FAST, SPHERES>(c, bvh, q0, q1, q2, o, d, best);
     }
     return bvh_pop(c, stack, stride);
 }
@@ -460,7 +594,8 @@ PT_DEV bool bvh_step(BvhCursor &c, const BvhView &bvh, V3 o, V3 d, BvhBest &best
 {
     if (c.node >= 0) {
         const float4 *q = bvh.nodes + (size_t)c.node * BVH_NODE_QUADS;
-        if (bvh_open_node(c, q[0], q[1], q[2], q[3], o, FAST ? best.lo : best.hi, stack, stride)) return true;
+        if (bvh_open_node(c, !FAST && bvh.sphere_term > 0.0f, q[0], q[1], q[2], q[3], o, FAST ? best.lo : best.hi, stack, stride))
+            return true;
     } else {
         const float4 *g = reinterpret_cast<const float4 *>(bvh.leaves + (size_t)(~c.node) * GEOM_STRIDE);
         bvh_test_leaf<FAST>(c, bvh, g[0], g[1], g[2], o, d, best);

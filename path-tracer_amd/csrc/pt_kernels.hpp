@@ -598,7 +598,8 @@ k_render_mega_tiled(RenderParams P)
 // 66 MB that every segment reads and writes through the caches, and the kernel took 3x as long.
 // COUNT: also counts the node records opened and the leaf triangles tested (stats[3], stats[4]):
 // an instantiation of its own (PT_MODE_COUNT_STEPS), the two counters cost registers.
-template <bool FAST, int WAVES = 6, bool COUNT = false>
+// SPHERES: the hierarchy holds spheres too (bvh_test_leaf).
+template <bool FAST, int WAVES = 6, bool COUNT = false, bool SPHERES = false>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 k_render_mega_bvh(RenderParams P)
 {
@@ -631,7 +632,7 @@ k_render_mega_bvh(RenderParams P)
                 need_path = !have_hit;
                 if (have_hit) {
                     // the winner's t and distance, once per segment (bvh_finish), then shading
-                    Hit h = bvh_finish<FAST>(cur, P.scene.bvh, P.scene.geom, P.scene.n_surfaces, ps.o, ps.d, best,
+                    Hit h = bvh_finish<FAST, SPHERES>(cur, P.scene.bvh, P.scene.geom, P.scene.n_surfaces, ps.o, ps.d, best,
                                              FAST ? 0.0f : __builtin_bit_cast(float, stack[BVH_STACK]));
                     if (h.idx < 0) h.dist = 0.0f;
                     if (shade_hit<FAST>(ps, P.scene, shade, h)) {
@@ -662,7 +663,7 @@ k_render_mega_bvh(RenderParams P)
                                                                ps.o, ps.d, P.stats + 1);
                 if (outside.idx >= 0) outside.idx = P.scene.loose[outside.idx];
                 if constexpr (!FAST) stack[BVH_STACK] = __builtin_bit_cast(int, outside.t);
-                bvh_begin<FAST>(cur, P.scene.bvh, ps.o, ps.d, outside);
+                bvh_begin<FAST, SPHERES>(cur, P.scene.bvh, ps.o, ps.d, outside);
                 best = bvh_best_from<FAST>(outside);
                 traversing = true;
                 n_seg++;
@@ -676,7 +677,7 @@ k_render_mega_bvh(RenderParams P)
                 if (!cur.direct) { if (cur.node >= 0) n_nodes++; else n_leaves++; }
             }
             // (a ray that needs the reference's own scan skips the traversal)
-            if (cur.direct || !bvh_advance<FAST>(cur, P.scene.bvh, q0, q1, q2, q3, ps.o, ps.d, best, stack, 1)) {
+            if (cur.direct || !bvh_advance<FAST, SPHERES>(cur, P.scene.bvh, q0, q1, q2, q3, ps.o, ps.d, best, stack, 1)) {
                 traversing = false;
                 have_hit = true;
             }

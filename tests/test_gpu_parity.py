@@ -687,6 +687,81 @@ def test_hierarchy_ties_and_duplicates(ctx, pt, orc):
     assert (want[0] >= 0).sum() > 5000
 
 
+def test_hierarchy_over_spheres(ctx, pt, orc):
+    """Small spheres are hierarchy leaves as well (from 32 of them on; AUTO builds one from some
+    130): a lattice of 343 spheres, some twice, between four large triangles and three large
+    spheres.  Unit directions, as every ray of a render has; also from inside spheres, from
+    their surfaces, grazing their silhouettes, and a ray whose direction is not a unit vector
+    (answered by the reference's scan of every surface).  Bit for bit against the oracle, and
+    the render through the hierarchy equals the render through the scan."""
+    rng = np.random.default_rng(21)
+    g = np.stack(np.meshgrid(*[np.arange(7)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    centres = -0.9 + 0.3 * g + rng.uniform(-0.04, 0.04, g.shape)
+    n_small = len(centres) + 40
+    surf = np.zeros(n_small + 7, dtype=pt.SURFACE)
+    surf["kind"][:n_small] = pt.SPHERE
+    surf["a"][:len(centres)] = centres
+    surf["b"][:len(centres), 0] = rng.uniform(0.05, 0.13, len(centres))
+    surf[len(centres):n_small] = surf[rng.integers(0, len(centres), 40)]          # exact duplicates
+    walls = n_small
+    for j, (a, b, c) in enumerate([((-3, 1.2, -3), (0, 1.2, 9), (3, 1.2, -3)), ((-3, -1.2, -3), (3, -1.2, -3), (0, -1.2, 9)),
+                                   ((-1.3, -3, -3), (-1.3, 0, 9), (-1.3, 3, -3)), ((1.3, -3, -3), (1.3, 3, -3), (1.3, 0, 9))]):
+        surf[walls + j]["kind"] = pt.TRIANGLE
+        surf[walls + j]["a"], surf[walls + j]["b"], surf[walls + j]["c"] = a, b, c
+    for j, (c, r) in enumerate([((0, 0, 4), 2.0), ((0, -3, 0), 1.5), ((2.5, 0, 0), 1.0)]):
+        surf[walls + 4 + j]["kind"] = pt.SPHERE
+        surf[walls + 4 + j]["a"] = c
+        surf[walls + 4 + j]["b"][0] = r
+    surf = surf[rng.permutation(len(surf))]
+    mats = np.zeros(3, dtype=pt.MATERIAL)
+    mats["type"] = [0, 1, 2]
+    mats["color"] = [(0.8, 0.7, 0.6), (1, 1, 1), (1, 1, 1)]
+    mats["emittance"][0] = (0.3, 0.3, 0.3)
+    surf["material"] = rng.integers(0, 3, len(surf))
+    cam = orc.camera_init([0, 0, -3.5], 0, 0, 96, 1, 96, 96)
+    osc = orc.Scene(surf.view(orc.SURFACE), mats.view(orc.MATERIAL), [0.1, 0.1, 0.2], cam)
+
+    m = 120000
+    o, d = random_rays(rng, m, 2.5)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d = d.astype(np.float32)
+    i0, _, p0 = orc.intersect_rays(osc, o[:m // 3], d[:m // 3])
+    o[:m // 3][i0 >= 0] = p0[i0 >= 0]                                   # from surfaces
+    sph = np.flatnonzero(surf["kind"] == pt.SPHERE)
+    k = rng.choice(sph, m // 6)
+    o[m // 3:m // 3 + m // 6] = surf["a"][k] + rng.uniform(-0.3, 0.3, (m // 6, 3)) * surf["b"][k, :1]      # from inside
+    k = rng.choice(sph, m // 6)
+    dirs = d[m // 2:m // 2 + m // 6].astype(np.float64)
+    perp = np.cross(dirs, rng.normal(size=dirs.shape))
+    perp /= np.linalg.norm(perp, axis=1, keepdims=True)
+    off = 1.0 + rng.choice([-1e-4, -1e-6, 0.0, 1e-6, 1e-4], (m // 6, 1))
+    o[m // 2:m // 2 + m // 6] = (surf["a"][k] + perp * surf["b"][k, :1] * off - 6.0 * dirs).astype(np.float32)    # grazing
+    d[-100:] *= 1.7                                                      # not unit vectors
+    want = orc.intersect_rays(osc, o, d)
+    assert (want[0] >= 0).mean() > 0.5
+    try:
+        images = {}
+        for accel in (pt.ACCEL_BVH, pt.ACCEL_AUTO, pt.ACCEL_NONE):
+            ctx.set_accel(accel)
+            ctx.set_scene(surf, mats, [0.1, 0.1, 0.2])
+            ctx.set_camera(cam.view(pt.CAMERA))
+            got = ctx.intersect_rays(o, d)
+            for g_, w_ in zip(got, want):
+                assert np.array_equal(g_, w_, equal_nan=True), accel
+            idx, dist = ctx.primary_hits()
+            oidx, odist = orc.primary_hits(osc)
+            assert np.array_equal(idx, oidx) and np.array_equal(dist, odist), accel
+            ctx.clear()
+            ctx.render(6, 0, 9, 0)
+            images[accel] = ctx.read_accum()[0]
+            c = ctx.counters()
+            assert c.accel == (pt.ACCEL_NONE if accel == pt.ACCEL_NONE else pt.ACCEL_BVH)
+        assert np.array_equal(images[pt.ACCEL_BVH], images[pt.ACCEL_NONE])
+        assert np.array_equal(images[pt.ACCEL_AUTO], images[pt.ACCEL_NONE])
+    finally:
+        ctx.set_accel(pt.ACCEL_AUTO)
+
+
 def test_hierarchy_on_the_million_triangle_scene(ctx, pt):
     """999,705 surfaces: hierarchy against the brute-force scan on the GPU, bit-exact, and a
     render that finishes."""

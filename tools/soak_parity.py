@@ -20,7 +20,8 @@ m = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
 ctx = pt.Context(0)
 bad_total = redone = rays = 0
 t0 = time.time()
-for seed in range(seeds):
+first_seed = int(os.environ.get("SOAK_FIRST_SEED", "0"))
+for seed in range(first_seed, first_seed + seeds):
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.integers(4, 400))
     surf = np.zeros(n, dtype=pt.SURFACE)
@@ -71,6 +72,24 @@ for seed in range(seeds):
         far = rng.choice([2.0, 5.0, 10.0, 20.0], (g, 1)) * spread
         o[-g:] = (point - far * dirs).astype(np.float32)
         d[-g:] = dirs.astype(np.float32)
+    # a twelfth of the rays graze a sphere's silhouette from far away (unit directions, passing the
+    # centre at radius * (1 +- 1e-6 .. 1e-3)): where the reference's d2 = L.L - tca^2 cancels most
+    sph_idx = np.flatnonzero(surf["kind"] == pt.SPHERE)
+    if len(sph_idx):
+        h = m // 12
+        lo = 2 * m // 3
+        k = rng.choice(sph_idx, h)
+        dirs = rng.normal(size=(h, 3))
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        perp = np.cross(dirs, rng.normal(size=(h, 3)))
+        perp /= np.linalg.norm(perp, axis=1, keepdims=True) + 1e-30
+        off = 1.0 + rng.choice([-1e-3, -1e-5, -1e-6, 0.0, 1e-6, 1e-5, 1e-3], (h, 1))
+        far = rng.choice([1.0, 3.0, 10.0, 30.0], (h, 1)) * spread
+        centre = surf["a"][k].astype(np.float64)
+        radius = surf["b"][k, :1].astype(np.float64)
+        o[lo:lo + h] = (centre + perp * radius * off - far * dirs).astype(np.float32)
+        dn = dirs.astype(np.float32)
+        d[lo:lo + h] = dn / np.linalg.norm(dn, axis=1, keepdims=True).astype(np.float32)
     want = orc.intersect_rays(osc, o, d)
     for accel in (pt.ACCEL_NONE, pt.ACCEL_BVH, pt.ACCEL_LDS_TILES):
         ctx.set_accel(accel)
@@ -81,6 +100,16 @@ for seed in range(seeds):
             b = np.flatnonzero(got[0] != want[0])[:3]
             print("seed %d accel %d: %d mismatches, e.g. rays %s got %s want %s" % (
                 seed, accel, bad, b.tolist(), got[0][b].tolist(), want[0][b].tolist()), flush=True)
+            if os.environ.get("SOAK_DETAILS"):
+                for r in b:
+                    print("  ray %d o %s d %s |d|^2-1 %.3g" % (r, o[r].tolist(), d[r].tolist(),
+                                                             float(np.dot(d[r].astype(np.float64), d[r].astype(np.float64)) - 1)))
+                    for tag, res in (("got", got), ("want", want)):
+                        i = int(res[0][r])
+                        desc = "none" if i < 0 else "%s a %s b %s c %s" % (
+                            "sphere" if surf["kind"][i] == pt.SPHERE else "triangle", surf["a"][i].tolist(),
+                            surf["b"][i].tolist(), surf["c"][i].tolist())
+                        print("   %s %d dist %r: %s" % (tag, i, float(res[1][r]), desc))
         bad_total += bad
     rays += m
     if seed % 10 == 9:
