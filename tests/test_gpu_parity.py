@@ -758,6 +758,21 @@ def test_hierarchy_over_spheres(ctx, pt, orc):
             assert c.accel == (pt.ACCEL_NONE if accel == pt.ACCEL_NONE else pt.ACCEL_BVH)
         assert np.array_equal(images[pt.ACCEL_BVH], images[pt.ACCEL_NONE])
         assert np.array_equal(images[pt.ACCEL_AUTO], images[pt.ACCEL_NONE])
+        # the same hierarchy under the wavefront layout (same paths, other order of additions)
+        # and under the FAST policy (same image statistically)
+        ctx.set_accel(pt.ACCEL_BVH)
+        ctx.set_scene(surf, mats, [0.1, 0.1, 0.2])
+        ctx.clear()
+        ctx.render(6, 0, 9, pt.MODE_WAVEFRONT)
+        wave = ctx.read_accum()[0]
+        assert np.allclose(wave, images[pt.ACCEL_NONE], rtol=1e-5, atol=1e-6)
+        ctx.clear()
+        ctx.render(64, 0, 9, pt.NUM_FAST)
+        fast = ctx.read_accum()[0]
+        ctx.clear()
+        ctx.render(64, 0, 9, pt.NUM_EXACT)
+        exact = ctx.read_accum()[0]
+        assert np.allclose(fast.mean((0, 1)), exact.mean((0, 1)), rtol=0.01)
     finally:
         ctx.set_accel(pt.ACCEL_AUTO)
 
