@@ -520,6 +520,43 @@ def test_headline_configuration_at_full_size(ctx, pt, golden):
     assert rms < 0.05
 
 
+def test_other_configurations_at_full_size(ctx, pt, golden):
+    """Configurations 3, 4 and 5 of the benchmark list at their own image sizes, through properties
+    that need no oracle run: bitwise repeatability, the segment count as a checksum of every
+    decision across the two kernel layouts, and (where the framing is the golden image's) level
+    and path length against the reference generator's converged image."""
+    g = golden("render_libc_64_4096spp.npz")
+    # 3: orange_plane 1600 x 1600, depth of field and antialiasing, one GPU's 128 spp
+    sc = pt.builtin_scene("orange_plane", 1600, 1600)
+    mega, cm = render(ctx, pt, sc, 128, seed=2, mode=pt.MODE_MEGAKERNEL)
+    wave, cw = render(ctx, pt, sc, 128, seed=2, mode=pt.MODE_WAVEFRONT)
+    assert cm.samples == 1600 * 1600 * 128 and cw.segments == cm.segments
+    assert np.allclose(wave, mega, rtol=2e-5, atol=1e-4)
+    assert np.allclose(mega.astype(np.float64).mean((0, 1)) / 128, g["orange_plane_mean"].astype(np.float64).mean((0, 1)), rtol=0.01)
+    assert abs(cm.segments / cm.samples - float(g["orange_plane_segments_per_sample"])) < 0.01
+    del mega, wave
+    # 4: glass_stress at 3840 x 2160 (16:9: another framing than the square golden)
+    sc = pt.builtin_scene("glass_stress", 3840, 2160)
+    a, ca = render(ctx, pt, sc, 64, seed=3, mode=pt.MODE_MEGAKERNEL)
+    b, cb = render(ctx, pt, sc, 64, seed=3, mode=pt.MODE_MEGAKERNEL)
+    assert np.array_equal(a, b) and ca.segments == cb.segments
+    w, cw = render(ctx, pt, sc, 64, seed=3, mode=pt.MODE_WAVEFRONT)
+    assert cw.segments == ca.segments and np.allclose(w, a, rtol=2e-5, atol=1e-4)
+    del b, w
+    big, cbig = render(ctx, pt, sc, 256, first=64, seed=3, mode=pt.MODE_MEGAKERNEL)
+    assert np.isfinite(big).all() and abs(cbig.segments / cbig.samples - ca.segments / ca.samples) < 0.01
+    assert np.allclose(big.astype(np.float64).mean((0, 1)) / 256, a.astype(np.float64).mean((0, 1)) / 64, rtol=0.01)
+    del a, big
+    # 5: the million-triangle field, 800 x 800, 64 spp, through the hierarchy
+    sc = pt.builtin_scene("heightfield", 800, 800)
+    a, ca = render(ctx, pt, sc, 64, seed=4, mode=pt.MODE_MEGAKERNEL)
+    b, cb = render(ctx, pt, sc, 64, seed=4, mode=pt.MODE_MEGAKERNEL)
+    assert ca.accel == pt.ACCEL_BVH and np.array_equal(a, b) and ca.segments == cb.segments
+    m16, c16 = render(ctx, pt, sc, 16, seed=4, mode=pt.MODE_MEGAKERNEL)
+    w16, cw16 = render(ctx, pt, sc, 16, seed=4, mode=pt.MODE_WAVEFRONT)
+    assert cw16.segments == c16.segments and np.allclose(w16, m16, rtol=2e-5, atol=1e-4)
+
+
 # ---------------------------------------------------------------- synthetic stress scenes
 
 def as_oracle_scene(orc, sc):
