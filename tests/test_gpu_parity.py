@@ -795,6 +795,16 @@ def test_hierarchy_over_spheres(ctx, pt, orc):
             assert c.accel == (pt.ACCEL_NONE if accel == pt.ACCEL_NONE else pt.ACCEL_BVH)
         assert np.array_equal(images[pt.ACCEL_BVH], images[pt.ACCEL_NONE])
         assert np.array_equal(images[pt.ACCEL_AUTO], images[pt.ACCEL_NONE])
+        # a launch large enough for the kernel variant of seven waves per SIMD (2e7 samples and more)
+        big = {}
+        for accel in (pt.ACCEL_BVH, pt.ACCEL_NONE):
+            ctx.set_accel(accel)
+            ctx.set_scene(surf, mats, [0.1, 0.1, 0.2])
+            ctx.set_camera(orc.camera_init([0, 0, -3.5], 0, 0, 512, 1, 512, 512).view(pt.CAMERA))
+            ctx.render(96, 0, 9, 0)
+            big[accel] = ctx.read_accum()[0]
+        assert np.array_equal(big[pt.ACCEL_BVH], big[pt.ACCEL_NONE])
+        ctx.set_camera(cam.view(pt.CAMERA))
         # the same hierarchy under the wavefront layout (same paths, other order of additions)
         # and under the FAST policy (same image statistically)
         ctx.set_accel(pt.ACCEL_BVH)
