@@ -810,6 +810,11 @@ def test_hierarchy_over_spheres(ctx, pt, orc):
         ctx.set_accel(pt.ACCEL_BVH)
         ctx.set_scene(surf, mats, [0.1, 0.1, 0.2])
         ctx.clear()
+        ctx.render(6, 0, 9, pt.MODE_COUNT_STEPS)
+        counted = ctx.read_accum()[0]
+        c = ctx.counters()
+        assert np.array_equal(counted, images[pt.ACCEL_NONE]) and c.node_steps > c.segments and c.leaf_steps > 0
+        ctx.clear()
         ctx.render(6, 0, 9, pt.MODE_WAVEFRONT)
         wave = ctx.read_accum()[0]
         assert np.allclose(wave, images[pt.ACCEL_NONE], rtol=1e-5, atol=1e-6)
