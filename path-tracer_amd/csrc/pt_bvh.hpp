@@ -589,16 +589,16 @@ PT_DEV bool bvh_advance(BvhCursor &c, const BvhView &bvh, float4 q0, float4 q1, 
 // Advances a traversal by one node or one leaf.  Returns false when the
 // traversal is complete.  stack: BVH_STACK ints per lane, lane-strided
 // (stack[level * stride]).
-template <bool FAST>
+template <bool FAST, bool SPHERES = true>
 PT_DEV bool bvh_step(BvhCursor &c, const BvhView &bvh, V3 o, V3 d, BvhBest &best, int *stack, int stride)
 {
     if (c.node >= 0) {
         const float4 *q = bvh.nodes + (size_t)c.node * BVH_NODE_QUADS;
-        if (bvh_open_node(c, !FAST && bvh.sphere_term > 0.0f, q[0], q[1], q[2], q[3], o, FAST ? best.lo : best.hi, stack, stride))
+        if (bvh_open_node(c, SPHERES && !FAST && bvh.sphere_term > 0.0f, q[0], q[1], q[2], q[3], o, FAST ? best.lo : best.hi, stack, stride))
             return true;
     } else {
         const float4 *g = reinterpret_cast<const float4 *>(bvh.leaves + (size_t)(~c.node) * GEOM_STRIDE);
-        bvh_test_leaf<FAST>(c, bvh, g[0], g[1], g[2], o, d, best);
+        bvh_test_leaf<FAST, SPHERES>(c, bvh, g[0], g[1], g[2], o, d, best);
     }
     return bvh_pop(c, stack, stride);
 }
@@ -663,17 +663,26 @@ PT_DEV void bvh_fetch_records(const float4 *records, uint32_t rec, char *lds_wav
 // the exact closest hit among the surfaces outside the hierarchy (idx < 0:
 // none); on exit it is the closest hit overall, with the reference's t and
 // distance (idx < 0: none).
+template <bool FAST, bool SPHERES>
+PT_DEV void closest_in_bvh_of(const BvhView &bvh, const float *geom, int n_surfaces, V3 o, V3 d, Hit &hit,
+                              int *stack, int stride)
+{
+    BvhCursor c;
+    bvh_begin<FAST, SPHERES>(c, bvh, o, d, hit);
+    BvhBest best = bvh_best_from<FAST>(hit);
+    const float outside_t = hit.t;
+    if (!c.direct)
+        while (bvh_step<FAST, SPHERES>(c, bvh, o, d, best, stack, stride)) {}
+    hit = bvh_finish<FAST, SPHERES>(c, bvh, geom, n_surfaces, o, d, best, outside_t);
+}
+
 template <bool FAST>
 PT_DEV void closest_in_bvh(const BvhView &bvh, const float *geom, int n_surfaces, V3 o, V3 d, Hit &hit,
                            int *stack, int stride)
 {
-    BvhCursor c;
-    bvh_begin<FAST>(c, bvh, o, d, hit);
-    BvhBest best = bvh_best_from<FAST>(hit);
-    const float outside_t = hit.t;
-    if (!c.direct)
-        while (bvh_step<FAST>(c, bvh, o, d, best, stack, stride)) {}
-    hit = bvh_finish<FAST>(c, bvh, geom, n_surfaces, o, d, best, outside_t);
+    // the same for every ray of a launch: the traversal with or without the sphere's code in its loop
+    if (bvh.sphere_term > 0.0f) closest_in_bvh_of<FAST, true>(bvh, geom, n_surfaces, o, d, hit, stack, stride);
+    else closest_in_bvh_of<FAST, false>(bvh, geom, n_surfaces, o, d, hit, stack, stride);
 }
 
 }  // namespace ptd
