@@ -970,6 +970,20 @@ def test_combined_device_image_can_be_adopted_and_tone_mapped(ctx, pt):
     assert n == 16 and np.allclose(got, want, rtol=1e-5, atol=1e-5)
     rgb = ctx.tonemap_rgb8()
     assert np.abs(rgb.astype(int) - want_rgb.astype(int)).max() <= 1
+    # The same with torch working on a side stream: render_share moves the library's launches
+    # onto torch's current stream, so the sum that follows (a stand-in for the reduce) is ordered
+    # behind the render kernels without any wait in between.
+    side = torch.cuda.Stream()
+    try:
+        with torch.cuda.stream(side):
+            parts = [torch.zeros(54, 96, 3, dtype=torch.float32, device="cuda") for _ in range(2)]
+            for rank in range(2):
+                pt_dist.render_share(ctx, parts[rank], 16, 2, rank, first_sample=0, seed=9)
+            total_side = parts[0] + parts[1]
+        side.synchronize()
+        assert torch.equal(total_side, total)
+    finally:
+        ctx.set_stream(None)
 
 
 def test_extreme_magnitudes_and_non_finite_inputs(ctx, pt, orc):
