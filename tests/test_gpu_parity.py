@@ -1103,6 +1103,19 @@ def test_soak_of_random_scenes_short():
     assert "360000 rays x 3 modes, 0 mismatches" in p.stdout
 
 
+def test_soak_of_random_renders_short():
+    """tools/soak_render.py (random scenes of triangles and spheres rendered through the scan and
+    through the hierarchy: the images must be equal bit for bit) on a few seeds."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_render.py"), "60"],
+                       capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    assert "total: 60 scenes" in p.stdout and "0 scenes differ" in p.stdout
+    assert "no hierarchy was built" not in p.stdout
+
+
 def test_scan_with_wave_level_early_outs_renders_like_the_oracle(ctx, pt, orc):
     """249 surfaces scanned linearly (PT_ACCEL_NONE): enough for the render kernel that asks the
     whole wave before finishing a surface's test; also bit-identical to the same scene rendered
