@@ -203,15 +203,42 @@ PT_DEV V3 ray_direction_by_pixel(const Camera &c, float u, float v)
     return Num<FAST>::normalize(mat_vec<FAST>(c, p));
 }
 
+// The render kernels' form of the jittered pinhole direction: rot * (u - W/2, v - H/2, focal) for
+// the pixel's integer corner once per work item (pixel_base), and per path the jitter along the
+// matrix's first two columns (a continuous function of random numbers: fused arithmetic, not the
+// reference's order of additions; pt_camera_rays keeps that order).
+PT_DEV V3 pixel_base(const Camera &c, int u, int v)
+{
+    return mat_vec<true>(c, v3((float)(u - c.width / 2), (float)(v - c.height / 2), c.focal));
+}
+
+PT_DEV V3 jittered_direction(const Camera &c, V3 base, float xi_u, float xi_v)
+{
+    const V3 p = v3(__builtin_fmaf(c.rot[3], xi_v, __builtin_fmaf(c.rot[0], xi_u, base.x)),
+                    __builtin_fmaf(c.rot[4], xi_v, __builtin_fmaf(c.rot[1], xi_u, base.y)),
+                    __builtin_fmaf(c.rot[5], xi_v, __builtin_fmaf(c.rot[2], xi_u, base.z)));
+    return Num<true>::normalize(p);
+}
+
+template <bool FAST>
+PT_DEV void lens_ray(const Camera &c, float xi_r, float xi_phi, V3 &origin, V3 &dir);
+
 // src/main.cpp:120-136: jitter, then the thin-lens origin/direction when DOF is on.
 template <bool FAST>
 PT_DEV void camera_ray(const Camera &c, int u, int v, float xi_u, float xi_v,
                        float xi_r, float xi_phi, V3 &origin, V3 &dir)
 {
+    origin = v3(c.pos[0], c.pos[1], c.pos[2]);
+    dir = ray_direction_by_pixel<FAST>(c, (float)u + xi_u, (float)v + xi_v);
+    lens_ray<FAST>(c, xi_r, xi_phi, origin, dir);
+}
+
+// The thin lens of src/main.cpp:124-136 applied to a pinhole ray (origin = the camera's position).
+template <bool FAST>
+PT_DEV void lens_ray(const Camera &c, float xi_r, float xi_phi, V3 &origin, V3 &dir)
+{
     using N = Num<FAST>;
     const V3 pos = v3(c.pos[0], c.pos[1], c.pos[2]);
-    origin = pos;
-    dir = ray_direction_by_pixel<FAST>(c, (float)u + xi_u, (float)v + xi_v);
     if (c.dof_on) {
         // camera.hpp:91-101: forward/downward/right = rot * unit axes = the columns
         // (the products with the 0 and 1 components are exact)

@@ -320,13 +320,17 @@ struct PathState {
 };
 
 // The start of a path: trace_rays' per-pixel set-up, src/main.cpp:120-136.
-PT_DEV void path_begin(PathState &ps, const Camera &cam, uint32_t pixel_key, uint32_t sample, int px, int py)
+// base: pixel_base of the path's pixel (the part of the ray set-up that is the same for every
+// sample of a pixel is formed once per work item).
+PT_DEV void path_begin(PathState &ps, const Camera &cam, uint32_t pixel_key, uint32_t sample, V3 base)
 {
     ps.rng = rng_path(pixel_key, sample);
     const float xu = rng_next(ps.rng), xv = rng_next(ps.rng);
     float xr = 0.0f, xp = 0.0f;
     if (cam.dof_on) { xr = rng_next(ps.rng); xp = rng_next(ps.rng); }
-    camera_ray<true>(cam, px, py, xu, xv, xr, xp, ps.o, ps.d);
+    ps.o = v3(cam.pos[0], cam.pos[1], cam.pos[2]);
+    ps.d = jittered_direction(cam, base, xu, xv);
+    lens_ray<true>(cam, xr, xp, ps.o, ps.d);
     ps.col = v3(0, 0, 0);
     ps.thr = v3(1, 1, 1);
     ps.depth = 0;
@@ -439,19 +443,18 @@ PT_DEV uint32_t pool_take(WorkPool &pool, bool want, uint32_t *queue_head, uint3
 struct ItemState {
     bool have;
     uint32_t item, pixel, pixel_key, s, s_end;
-    int px, py;
+    V3 base;            // pixel_base of the item's pixel
     V3 sum;
 };
 
-PT_DEV void item_open(ItemState &it, uint32_t item, int width, uint32_t n_pixels, uint32_t first_sample,
+PT_DEV void item_open(ItemState &it, uint32_t item, const Camera &cam, uint32_t n_pixels, uint32_t first_sample,
                       uint32_t spp, uint32_t chunk_len, uint32_t seed_mix)
 {
     it.item = item;
     it.have = true;
     const uint32_t chunk = item / n_pixels;
     it.pixel = item - chunk * n_pixels;
-    it.px = (int)(it.pixel % (uint32_t)width);
-    it.py = (int)(it.pixel / (uint32_t)width);
+    it.base = pixel_base(cam, (int)(it.pixel % (uint32_t)cam.width), (int)(it.pixel / (uint32_t)cam.width));
     it.s = first_sample + chunk * chunk_len;
     const uint32_t last = first_sample + spp;
     it.s_end = it.s + chunk_len < last ? it.s + chunk_len : last;
@@ -496,7 +499,7 @@ k_render_mega(RenderParams P)
     }
 
     WorkPool pool = {0, 0, false};
-    ItemState it = {false, 0, 0, 0, 0, 0, 0, 0, v3(0, 0, 0)};
+    ItemState it = {false, 0, 0, 0, 0, 0, v3(0, 0, 0), v3(0, 0, 0)};
     bool need_path = true;
     PathState ps = {v3(0, 0, 0), v3(0, 0, 1), v3(1, 1, 1), v3(0, 0, 0), {0, 0}, 0};
     unsigned long long n_seg = 0;
@@ -508,11 +511,11 @@ k_render_mega(RenderParams P)
             const uint32_t got = pool_take(pool, want, P.queue_head, P.n_items, P.pool_batch);
             if (want) {
                 if (got == NO_ITEM) break;      // queue empty: this lane retires
-                item_open(it, got, P.cam.width, P.n_pixels, P.first_sample, P.spp, P.chunk_len, P.seed_mix);
+                item_open(it, got, P.cam, P.n_pixels, P.first_sample, P.spp, P.chunk_len, P.seed_mix);
             }
         }
         if (need_path) {
-            path_begin(ps, P.cam, it.pixel_key, it.s, it.px, it.py);
+            path_begin(ps, P.cam, it.pixel_key, it.s, it.base);
             need_path = false;
         }
         const bool ended = path_segment<FAST, KIND, SPHERE_SKIP>(ps, P.scene, shade, lds_shade, P.stats + 1);
@@ -539,7 +542,7 @@ k_render_mega_tiled(RenderParams P)
     __shared__ __align__(16) float tiles[2 * SCAN_TILE_FLOATS];
     const float *shade = P.scene.shade;
     WorkPool pool = {0, 0, false};
-    ItemState it = {false, 0, 0, 0, 0, 0, 0, 0, v3(0, 0, 0)};
+    ItemState it = {false, 0, 0, 0, 0, 0, v3(0, 0, 0), v3(0, 0, 0)};
     bool need_path = true, alive = true;
     PathState ps = {v3(0, 0, 0), v3(0, 0, 1), v3(1, 1, 1), v3(0, 0, 0), {0, 0}, 0};
     unsigned long long n_seg = 0;
@@ -551,12 +554,12 @@ k_render_mega_tiled(RenderParams P)
             const uint32_t got = pool_take(pool, want, P.queue_head, P.n_items, P.pool_batch);
             if (want) {
                 if (got == NO_ITEM) alive = false;
-                else item_open(it, got, P.cam.width, P.n_pixels, P.first_sample, P.spp, P.chunk_len, P.seed_mix);
+                else item_open(it, got, P.cam, P.n_pixels, P.first_sample, P.spp, P.chunk_len, P.seed_mix);
             }
         }
         if (__syncthreads_count(alive) == 0) break;             // workgroup-uniform
         if (alive && need_path) {
-            path_begin(ps, P.cam, it.pixel_key, it.s, it.px, it.py);
+            path_begin(ps, P.cam, it.pixel_key, it.s, it.base);
             need_path = false;
         }
         const V3 o = alive ? ps.o : v3(0, 0, 0), d = alive ? ps.d : v3(0, 0, 1);
@@ -607,7 +610,7 @@ k_render_mega_bvh(RenderParams P)
     char *lds_wave = fetch_lds + (threadIdx.x / 64) * BVH_FETCH_LDS;
     const float *shade = P.scene.shade;
     WorkPool pool = {0, 0, false};
-    ItemState it = {false, 0, 0, 0, 0, 0, 0, 0, v3(0, 0, 0)};
+    ItemState it = {false, 0, 0, 0, 0, 0, v3(0, 0, 0), v3(0, 0, 0)};
     PathState ps = {v3(0, 0, 0), v3(0, 0, 1), v3(1, 1, 1), v3(0, 0, 0), {0, 0}, 0};
     BvhBest best = {BVH_NO_HIT, 0.0f, 0.0f};
     BvhCursor cur;
@@ -649,11 +652,11 @@ k_render_mega_bvh(RenderParams P)
                 const uint32_t got = pool_take(pool, want, P.queue_head, P.n_items, P.pool_batch);
                 if (want) {
                     if (got == NO_ITEM) alive = false;       // queue empty: this lane retires
-                    else item_open(it, got, P.cam.width, P.n_pixels, P.first_sample, P.spp, P.chunk_len, P.seed_mix);
+                    else item_open(it, got, P.cam, P.n_pixels, P.first_sample, P.spp, P.chunk_len, P.seed_mix);
                 }
             }
             if (waits && alive) {
-                if (need_path) path_begin(ps, P.cam, it.pixel_key, it.s, it.px, it.py);
+                if (need_path) path_begin(ps, P.cam, it.pixel_key, it.s, it.base);
                 // the surfaces outside the hierarchy first, then the hierarchy
                 Hit outside;
                 if constexpr (FAST)
@@ -754,7 +757,7 @@ k_wf_generate(WfParams P)
     const uint32_t s = i / P.n_pixels, pixel = i - s * P.n_pixels;
     PathState ps;
     path_begin(ps, P.cam, rng_pixel(P.seed_mix, pixel), P.first_sample + s,
-               (int)(pixel % (uint32_t)P.cam.width), (int)(pixel / (uint32_t)P.cam.width));
+               pixel_base(P.cam, (int)(pixel % (uint32_t)P.cam.width), (int)(pixel / (uint32_t)P.cam.width)));
     const uint32_t shard = blockIdx.x % WF_SHARDS, local = blockIdx.x / WF_SHARDS;
     wf_store(P.in, shard * P.shard_cap + local * BLOCK + threadIdx.x, ps, i);
 }
