@@ -443,6 +443,43 @@ int with_variant(bool fast, int kind, F &&f)
     return f.template operator()<false, SCENE_BVH>();
 }
 
+// Rays per lane of a closest-hit query (k_primary_hits_multi, k_intersect_rays_multi), or 0 for
+// the one-ray kernels.  The N-ray kernels are the FAST policy's (measured on 16.8 M camera rays of
+// cornell_2: 0.115 ms with one ray per lane, 0.103 / 0.097 / 0.094 with 2 / 4 / 8); the EXACT scan
+// compiles to more instructions per ray in that form and keeps the one-ray kernels (0.191 against
+// 0.193 / 0.185 / 0.214 ms), as do scenes with a hierarchy, scenes whose records do not fit the
+// kernels' LDS copy, and the LDS-tiled scan.  More rays per lane mean fewer workgroups, so small
+// queries take fewer.  PT_QUERY_RAYS (0, 1, 2, 4, 8) overrides the choice, for either policy:
+// for measurements and for the parity tests of every form.
+int query_rays_per_lane(const pt_ctx *ctx, long long n_rays, bool fast)
+{
+    if (ctx->accel == PT_ACCEL_LDS_TILES || ctx->n_bvh > 0 || ctx->n_surfaces < 1 ||
+        ctx->n_surfaces > QUERY_MAX_SURFACES)
+        return 0;
+    if (const char *e = getenv("PT_QUERY_RAYS")) {
+        const int v = atoi(e);
+        if (v == 0 || v == 1 || v == 2 || v == 4 || v == 8) return v;
+    }
+    if (!fast) return 0;
+    // rays per lane if every CU had one workgroup
+    const long long per_lane = n_rays / ((long long)std::max(ctx->num_cus, 1) * BLOCK);
+    if (per_lane >= 64) return 8;
+    if (per_lane >= 32) return 4;
+    if (per_lane >= 16) return 2;
+    return 0;
+}
+
+template <class F>
+int with_rays_per_lane(int n, F &&f)
+{
+    switch (n) {
+    case 1: return f.template operator()<1>();
+    case 2: return f.template operator()<2>();
+    case 4: return f.template operator()<4>();
+    default: return f.template operator()<8>();
+    }
+}
+
 // Surfaces every segment scans linearly: all of them, or those outside the hierarchy.
 static double ctx_scan_count(const pt_ctx *ctx) { return ctx->n_bvh > 0 ? ctx->n_loose : ctx->n_surfaces; }
 
@@ -1139,8 +1176,20 @@ int pt_primary_hits(pt_ctx *ctx, int32_t *surf_idx, float *distance, int numeric
     if ((rc = dev_alloc(ctx, &d_idx.p, (size_t)n))) return rc;
     if ((rc = dev_alloc(ctx, &d_dist.p, (size_t)n))) return rc;
     const void *kernel = nullptr;
+    const int per_lane = query_rays_per_lane(ctx, n, (numeric & PT_NUM_FAST) != 0);
+    unsigned grid = blocks_for(n);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     rc = with_variant((numeric & PT_NUM_FAST) != 0, scene_kind(ctx), [&]<bool FAST, int KIND>() {
+        if (per_lane > 0) {
+            return with_rays_per_lane(per_lane, [&]<int N>() {
+                grid = (unsigned)((n + (long long)BLOCK * N - 1) / ((long long)BLOCK * N));
+                kernel = reinterpret_cast<const void *>(&k_primary_hits_multi<FAST, N>);
+                hipLaunchKernelGGL((k_primary_hits_multi<FAST, N>), dim3(grid), dim3(BLOCK),
+                                   (size_t)ctx->n_surfaces * GEOM_STRIDE * sizeof(float), ctx->stream,
+                                   ctx->cam, scene_view(ctx), d_idx.p, d_dist.p);
+                return (int)PT_OK;
+            });
+        }
         if (ctx->accel == PT_ACCEL_LDS_TILES) {
             kernel = reinterpret_cast<const void *>(&k_primary_hits_tiled<FAST>);
             hipLaunchKernelGGL(k_primary_hits_tiled<FAST>, dim3(blocks_for(n)), dim3(BLOCK), 0, ctx->stream,
@@ -1157,7 +1206,7 @@ int pt_primary_hits(pt_ctx *ctx, int32_t *surf_idx, float *distance, int numeric
     HIP_TRY(ctx, hipMemcpyAsync(surf_idx, d_idx.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(distance, d_dist.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return note_query(ctx, n, kernel, blocks_for(n), scene_kind(ctx));
+    return note_query(ctx, n, kernel, grid, scene_kind(ctx));
 }
 
 int pt_intersect_rays(pt_ctx *ctx, const float *origin, const float *dir, int64_t n,
@@ -1176,8 +1225,20 @@ int pt_intersect_rays(pt_ctx *ctx, const float *origin, const float *dir, int64_
     if ((rc = dev_alloc(ctx, &d_dist.p, (size_t)n))) return rc;
     if ((rc = dev_alloc(ctx, &d_pt.p, (size_t)n * 3))) return rc;
     const void *kernel = nullptr;
+    const int per_lane = query_rays_per_lane(ctx, n, (numeric & PT_NUM_FAST) != 0);
+    unsigned grid = blocks_for(n);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     rc = with_variant((numeric & PT_NUM_FAST) != 0, scene_kind(ctx), [&]<bool FAST, int KIND>() {
+        if (per_lane > 0) {
+            return with_rays_per_lane(per_lane, [&]<int N>() {
+                grid = (unsigned)((n + (long long)BLOCK * N - 1) / ((long long)BLOCK * N));
+                kernel = reinterpret_cast<const void *>(&k_intersect_rays_multi<FAST, N>);
+                hipLaunchKernelGGL((k_intersect_rays_multi<FAST, N>), dim3(grid), dim3(BLOCK),
+                                   (size_t)ctx->n_surfaces * GEOM_STRIDE * sizeof(float), ctx->stream,
+                                   scene_view(ctx), d_o.p, d_d.p, (long long)n, d_idx.p, d_dist.p, d_pt.p);
+                return (int)PT_OK;
+            });
+        }
         if (ctx->accel == PT_ACCEL_LDS_TILES) {
             kernel = reinterpret_cast<const void *>(&k_intersect_rays_tiled<FAST>);
             hipLaunchKernelGGL(k_intersect_rays_tiled<FAST>, dim3(blocks_for(n)), dim3(BLOCK), 0, ctx->stream,
@@ -1195,7 +1256,7 @@ int pt_intersect_rays(pt_ctx *ctx, const float *origin, const float *dir, int64_
     HIP_TRY(ctx, hipMemcpyAsync(distance, d_dist.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(point, d_pt.p, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return note_query(ctx, n, kernel, blocks_for(n), scene_kind(ctx));
+    return note_query(ctx, n, kernel, grid, scene_kind(ctx));
 }
 
 int pt_camera_rays(pt_ctx *ctx, const int32_t *px, const float *xi, int64_t n,

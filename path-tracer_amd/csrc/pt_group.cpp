@@ -91,6 +91,7 @@ struct pt_group {
     size_t floats = 0;
     uint64_t total_samples = 0;
     bool dirty = false;               // the parts hold samples the first context's image lacks
+    bool poisoned = false;            // a render failed after some members had added their shares (until pt_group_clear)
     std::string error;
 };
 
@@ -153,6 +154,11 @@ const char *pt_group_last_error(pt_group *g) { return g ? g->error.c_str() : g_g
 
 void pt_group_share(uint32_t spp_total, int n, int rank, uint32_t first_sample, uint32_t *first, uint32_t *count)
 {
+    if (n < 1 || rank < 0 || rank >= n) {           // no such member: an empty share
+        if (first) *first = first_sample;
+        if (count) *count = 0;
+        return;
+    }
     const uint64_t lo = (uint64_t)rank * spp_total / (uint64_t)n, hi = (uint64_t)(rank + 1) * spp_total / (uint64_t)n;
     if (first) *first = first_sample + (uint32_t)lo;
     if (count) *count = (uint32_t)(hi - lo);
@@ -288,6 +294,7 @@ int pt_group_clear(pt_group *g)
     if (rc != PT_OK) return member_failed(g, 0, rc);
     g->total_samples = 0;
     g->dirty = false;
+    g->poisoned = false;
     return PT_OK;
 }
 
@@ -325,13 +332,19 @@ int pt_group_render(pt_group *g, uint32_t spp_total, uint32_t first_sample, uint
     if (!g) return gfail(nullptr, PT_E_INVALID, "null group");
     if (!g->floats) return gfail(g, PT_E_INVALID, "pt_group_set_camera has not been called");
     if (spp_total == 0) return gfail(g, PT_E_INVALID, "spp must be positive");
+    if (g->poisoned) return gfail(g, PT_E_INVALID, "an earlier pt_group_render failed part-way: call pt_group_clear");
     const int n = (int)g->ctx.size();
     for (int i = 0; i < n; i++) {           // enqueued on every device's stream before anything waits
         uint32_t first = 0, count = 0;
         pt_group_share(spp_total, n, i, first_sample, &first, &count);
         if (count == 0) continue;
         const int rc = pt_render_into(g->ctx[i], g->part[i], count, first, seed, mode);
-        if (rc != PT_OK) return member_failed(g, (size_t)i, rc);
+        if (rc != PT_OK) {
+            // members 0..i-1 have already added their shares to their images: the images no longer
+            // add up to a whole number of samples per pixel, and stay unusable until they are cleared
+            if (i > 0) g->poisoned = true;
+            return member_failed(g, (size_t)i, rc);
+        }
     }
     g->total_samples += spp_total;
     g->dirty = true;
@@ -344,11 +357,13 @@ int pt_group_reduce(pt_group *g)
     if (!g->floats) return gfail(g, PT_E_INVALID, "pt_group_set_camera has not been called");
     Rccl *r = rccl();
     if (!r) return gfail(g, PT_E_HIP, "%s", g_rccl.error.c_str());
+    if (g->poisoned) return gfail(g, PT_E_INVALID, "an earlier pt_group_render failed part-way: call pt_group_clear");
     const int n = (int)g->ctx.size();
     ncclResult_t nr = r->GroupStart();
+    if (nr != ncclSuccess) return gfail(g, PT_E_HIP, "ncclGroupStart: %s", r->GetErrorString(nr));
     for (int i = 0; i < n && nr == ncclSuccess; i++)
         nr = r->Reduce(g->part[i], i == 0 ? g->sum : nullptr, g->floats, ncclFloat, ncclSum, 0, g->comms[i], g->streams[i]);
-    const ncclResult_t ne = r->GroupEnd();
+    const ncclResult_t ne = r->GroupEnd();          // closes the group that GroupStart opened, also after a failed call
     if (nr == ncclSuccess) nr = ne;
     if (nr != ncclSuccess) return gfail(g, PT_E_HIP, "ncclReduce: %s", r->GetErrorString(nr));
     int rc = wait_all(g);

@@ -3,6 +3,7 @@
 
 #include "pt_device.hpp"
 #include "pt_bvh.hpp"
+#include "pt_query.hpp"
 
 namespace ptd {
 
@@ -119,6 +120,72 @@ k_intersect_rays(SceneView scene, const float *org, const float *dir,
     V3 pt = v3(0, 0, 0);
     if (h.idx >= 0) pt = Num<FAST>::along(o, d, h.t);
     point[3 * i] = pt.x; point[3 * i + 1] = pt.y; point[3 * i + 2] = pt.z;
+}
+
+// The two query kernels with N rays per lane (pt_query.hpp): scenes of up to QUERY_MAX_SURFACES
+// scanned surfaces and no hierarchy.  A workgroup takes BLOCK * N consecutive rays, lane t the rays
+// t, t + BLOCK, ... of them (so a wave's loads and stores of one k are contiguous).
+template <bool FAST, int N>
+__global__ void __launch_bounds__(BLOCK)
+k_primary_hits_multi(Camera cam, SceneView scene, int32_t *idx, float *dist)
+{
+    extern __shared__ __align__(16) float lds[];
+    query_stage_records(FAST ? scene.lean : scene.geom, scene.n_scan, lds);
+    const uint32_t n = (uint32_t)cam.width * (uint32_t)cam.height;
+    const uint32_t width = (uint32_t)cam.width;
+    const uint32_t step_y = (uint32_t)BLOCK / width, step_x = (uint32_t)BLOCK - step_y * width;
+    const uint32_t p0 = blockIdx.x * (uint32_t)(BLOCK * N) + threadIdx.x;
+    // pixel of ray k: p0 + k * BLOCK, stepped in (x, y) without a division per ray
+    uint32_t y = p0 / width, x = p0 - y * width;
+    V3 o[N], d[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        o[k] = v3(cam.pos[0], cam.pos[1], cam.pos[2]);
+        d[k] = ray_direction_by_pixel<FAST>(cam, (float)x, (float)y);
+        x += step_x; y += step_y;
+        if (x >= width) { x -= width; y++; }
+    }
+    Hit h[N];
+    closest_hits<FAST, N>(lds, scene.geom, scene.n_scan, o, d, h);
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const uint32_t p = p0 + (uint32_t)(k * BLOCK);
+        if (p < n) {
+            idx[p] = h[k].idx;
+            dist[p] = h[k].idx < 0 ? 0.0f : h[k].dist;
+        }
+    }
+}
+
+template <bool FAST, int N>
+__global__ void __launch_bounds__(BLOCK)
+k_intersect_rays_multi(SceneView scene, const float *org, const float *dir,
+                       long long n, int32_t *idx, float *dist, float *point)
+{
+    extern __shared__ __align__(16) float lds[];
+    query_stage_records(FAST ? scene.lean : scene.geom, scene.n_scan, lds);
+    const long long i0 = (long long)blockIdx.x * (BLOCK * N) + threadIdx.x;
+    V3 o[N], d[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        long long i = i0 + k * BLOCK;
+        if (i >= n) i = n - 1;                                  // a ray to keep the lane company; not stored
+        o[k] = v3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
+        d[k] = v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+    }
+    Hit h[N];
+    closest_hits<FAST, N>(lds, scene.geom, scene.n_scan, o, d, h);
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const long long i = i0 + k * BLOCK;
+        if (i < n) {
+            idx[i] = h[k].idx;
+            dist[i] = h[k].idx < 0 ? 0.0f : h[k].dist;
+            V3 pt = v3(0, 0, 0);
+            if (h[k].idx >= 0) pt = Num<FAST>::along(o[k], d[k], h[k].t);
+            point[3 * i] = pt.x; point[3 * i + 1] = pt.y; point[3 * i + 2] = pt.z;
+        }
+    }
 }
 
 // ---- the linear scan with records staged through LDS ---------------------------

@@ -19,6 +19,12 @@ def test_group_share_tiles_the_range(pt):
                 pos += count
 
 
+def test_group_share_of_a_member_that_does_not_exist_is_empty(pt):
+    # no division by zero for n < 1, and no samples beyond the request for a rank outside [0, n)
+    for n, rank in ((0, 0), (-1, 0), (-5, -5), (4, -1), (4, 4), (4, 9), (1, 1)):
+        assert pt.group_share(1000, n, rank, 7) == (7, 0)
+
+
 @pytest.mark.gpu
 def test_group_image_equals_one_context(ctx, pt):
     import torch
@@ -77,3 +83,61 @@ def test_group_errors(pt):
     with pt.Group([0]) as g:
         with pytest.raises(pt.PtError):
             g.render(1)                   # no camera yet
+
+
+@pytest.mark.gpu
+def test_group_can_be_made_and_destroyed_repeatedly(ctx, pt):
+    """Communicator, stream and image lifetimes: build, render, reduce, destroy - three times, and
+    the third group's image equals the first's bit for bit (the same devices, the same shares)."""
+    import torch
+    n = torch.cuda.device_count()
+    sc = pt.builtin_scene("orange_plane", 96, 64)
+    images = []
+    for _ in range(3):
+        with pt.Group(list(range(n))) as g:
+            g.load(sc)
+            g.render(12, 0, 3, 0)
+            g.reduce()
+            g.render(4, 12, 3, 0)          # left unreduced: read_accum reduces
+            got, total = g.read_accum()
+            assert total == 16
+            images.append(got)
+    assert np.array_equal(images[0], images[1]) and np.array_equal(images[0], images[2])
+    ctx.load(sc)
+    ctx.render(16, 0, 3, 0)
+    want, _ = ctx.read_accum()
+    assert np.allclose(images[0], want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_two_contexts_on_one_device_interleaved_from_one_thread(pt):
+    """What pt_group_render relies on: render calls on different contexts, each with a stream of
+    its own, enqueued from one thread without waiting, do not disturb each other."""
+    import torch
+    sc_a = pt.builtin_scene("cornell_2", 120, 80)
+    sc_b = pt.builtin_scene("red_corner", 64, 96)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    with pt.Context(0) as a, pt.Context(0) as b, pt.Context(0) as alone:
+        a.load(sc_a)
+        b.load(sc_b)
+        a.set_stream(sa.cuda_stream)
+        b.set_stream(sb.cuda_stream)
+        img_a = torch.zeros(80, 120, 3, dtype=torch.float32, device="cuda")
+        img_b = torch.zeros(96, 64, 3, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        for k in range(6):                  # enqueued alternately, nothing waits in between
+            a.render_into(img_a.data_ptr(), 5, 5 * k, 9, 0)
+            b.render_into(img_b.data_ptr(), 3, 3 * k, 4, pt.NUM_FAST)
+        sa.synchronize()
+        sb.synchronize()
+        alone.load(sc_a)
+        alone.render(30, 0, 9, 0)
+        want_a, _ = alone.read_accum()
+        alone.load(sc_b)
+        alone.render(18, 0, 4, pt.NUM_FAST)
+        want_b, _ = alone.read_accum()
+        # the same work items in the same order per context: only the split into launches differs
+        assert np.allclose(img_a.cpu().numpy(), want_a, rtol=1e-5, atol=1e-5)
+        assert np.allclose(img_b.cpu().numpy(), want_b, rtol=1e-5, atol=1e-5)
+        a.set_stream(0)
+        b.set_stream(0)

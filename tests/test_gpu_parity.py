@@ -115,6 +115,43 @@ def test_intersect_rays_bit_exact(ctx, pt, orc, name):
     assert (idx >= 0).sum() > 1000
 
 
+@pytest.mark.parametrize("per_lane", [0, 1, 2, 4, 8])
+def test_query_kernels_with_several_rays_per_lane(ctx, pt, orc, per_lane, monkeypatch):
+    """The closest-hit query kernels that carry N rays per lane (records broadcast from LDS into
+    vector registers) against the oracle, every N forced in turn through PT_QUERY_RAYS (0: the
+    one-ray kernels), on image sizes and ray counts that leave the last workgroup ragged: EXACT
+    bit for bit; FAST against EXACT as the one-ray kernels are held."""
+    monkeypatch.setenv("PT_QUERY_RAYS", str(per_lane))
+    rng = np.random.default_rng(100 + per_lane)
+    for name, w, h in (("cornell_2", 333, 77), ("orange_plane", 7, 3), ("cornell", 801, 130)):
+        load(ctx, pt.builtin_scene(name, w, h))
+        osc = orc.builtin_scene(name, w, h)
+        idx, dist = ctx.primary_hits()
+        oidx, odist = orc.primary_hits(osc)
+        assert np.array_equal(idx, oidx) and np.array_equal(dist, odist), (name, per_lane)
+        if per_lane:
+            assert ctx.counters().grid_blocks == -(-w * h // (256 * per_lane))
+        fidx, fdist = ctx.primary_hits(pt.NUM_FAST)
+        assert (fidx != oidx).sum() <= max(2, idx.size // 10000)
+        same = (fidx == oidx) & (oidx >= 0)
+        assert np.allclose(fdist[same], odist[same], rtol=3e-5)
+        n = 256 * max(per_lane, 1) * 3 + 17
+        o, d = random_rays(rng, n)
+        i0, _, p0 = orc.intersect_rays(osc, o[: n // 4], d[: n // 4])
+        o[: n // 4][i0 >= 0] = p0[i0 >= 0]               # rays that start on surfaces
+        d[n // 2: n // 2 + 100] *= rng.uniform(0.5, 2.0, (100, 1)).astype(np.float32)
+        got = ctx.intersect_rays(o, d)
+        want = orc.intersect_rays(osc, o, d)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b), (name, per_lane)
+        fgot = ctx.intersect_rays(o, d, pt.NUM_FAST)
+        assert (fgot[0] != want[0]).sum() <= max(3, n // 2000)
+        for m in (1, 255, 257):                          # fewer rays than one workgroup's batch
+            got = ctx.intersect_rays(o[:m], d[:m])
+            for a, b in zip(got, want):
+                assert np.array_equal(a, b[:m])
+
+
 def test_intersect_edge_cases(ctx, pt, orc):
     """Coincident surfaces (lowest index wins), grazing and degenerate rays, rays
     parallel to a triangle, a ray starting inside a sphere, an empty batch."""
