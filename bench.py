@@ -101,15 +101,38 @@ def intersection_kernel(pt_amd, scene_name, device):
     return out
 
 
-def pmc_summary():
+def kernel_source_hash():
+    """SHA-1 over the device sources the render kernel is built from (sorted by name), the
+    stamp tools/make_profile_summary.py stores beside the counters it collects."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    src = os.path.join(ROOT, "path-tracer_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(src, "*.hpp")) + glob.glob(os.path.join(src, "*.hip"))):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def pmc_summary(kernel_ms):
     """The committed rocprofv3 PMC summary of the headline launch (tools/profile_gpu.sh +
-    tools/make_profile_summary.py --traffic), or {} if there is none."""
+    tools/make_profile_summary.py --traffic).  The counters come from a profiler run, not from
+    this run, so they are reported only when they describe the kernel that just ran: the
+    summary's source hash must equal the hash of today's device sources and its kernel time must
+    lie within 5 % of this run's.  Returns (summary or {}, None or why it was not used)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f)
+            pmc = json.load(f)
     except (OSError, ValueError):
-        return {}
+        return {}, "profiles/pmc_traffic.json is missing"
+    if pmc.get("source_sha1") != kernel_source_hash():
+        return {}, "profiles/pmc_traffic.json was collected on other device sources"
+    ref_ms = pmc.get("kernel_ms")
+    if not ref_ms or abs(kernel_ms - ref_ms) > 0.05 * ref_ms:
+        return {}, "profiles/pmc_traffic.json: kernel %.2f ms then, %.2f ms now" % (ref_ms or 0.0, kernel_ms)
+    return pmc, None
 
 
 def launch_ranks(n):
@@ -150,11 +173,25 @@ def main():
     backend = os.environ.get("PT_BENCH_BACKEND", "nccl")
     device = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device)
-    if world > 1:
+    # PT_BENCH_FORCE_PG=1: also at one rank, make the process group and run the per-step reduce
+    # (torch's RCCL path end to end on a one-GPU box; rendezvous on 127.0.0.1 when nothing set it up)
+    force_pg = os.environ.get("PT_BENCH_FORCE_PG") == "1"
+    if world > 1 or force_pg:
+        import datetime
+        if "MASTER_ADDR" not in os.environ:
+            import socket
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+        # a rank that dies before a collective must not leave the others waiting for the driver's
+        # time limit: rendezvous and every collective give up after two minutes
+        limit = datetime.timedelta(seconds=int(os.environ.get("PT_BENCH_PG_TIMEOUT", "120")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+            dist.init_process_group("nccl", rank=rank, world_size=world, timeout=limit,
+                                    device_id=torch.device("cuda", device))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=limit)
 
     width, height = args.size
     mode = (pt_amd.MODE_WAVEFRONT if args.layout == "wavefront" else pt_amd.MODE_MEGAKERNEL) | \
@@ -171,10 +208,10 @@ def main():
         # step i renders global samples [i*world*spp, (i+1)*world*spp), split over the ranks
         pt_dist.render_share(ctx, accum, args.spp * world, world, rank,
                              first_sample=i * world * args.spp, seed=args.seed, mode=mode)
-        pt_dist.reduce_image(accum, dst=0)       # one RCCL reduce; a no-op on one GPU
+        pt_dist.reduce_image(accum, dst=0, always=force_pg)    # one RCCL reduce; a no-op without a process group
 
     def fence():
-        if world > 1:
+        if world > 1 or force_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -207,7 +244,7 @@ def main():
         # counters belong to the headline launch only
         headline = (args.scene == "cornell_2" and (width, height, args.spp) == (800, 800, 1024) and
                     args.layout == "megakernel" and args.numeric == "exact")
-        pmc = pmc_summary() if headline else {}
+        pmc, pmc_stale = pmc_summary(avg_ms) if headline else ({}, None)
         out = {
             "metric": "Msamples/sec, 800x800 Cornell box (diffuse+mirror+glass)",
             "value": value,
@@ -241,6 +278,10 @@ def main():
             "vgprs": int(c.vgprs),
             "grid_blocks": int(c.grid_blocks),
         }
+        if pmc_stale:
+            out["roofline"]["traffic_stale"] = pmc_stale
+        if force_pg:
+            out["config"]["process_group"] = "%s, world %d" % (backend, world)
         if args.layout == "megakernel":
             # persistent workgroups of four waves, one per SIMD: workgroups per CU = waves per SIMD
             cus = torch.cuda.get_device_properties(device).multi_processor_count
@@ -276,9 +317,21 @@ def main():
         print(json.dumps(out), flush=True)
 
     ctx.close()
-    if world > 1:
+    if world > 1 or force_pg:
         dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:
+        # any rank's failure ends its process with a non-zero code at once (no interpreter
+        # shutdown that could wait on a collective), so that torch.distributed.run tears the
+        # other ranks down instead of leaving them to a time limit
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        sys.stdout.flush()
+        os._exit(1)

@@ -200,7 +200,9 @@ int pt_render_into(pt_ctx *ctx, float *accum_device, uint32_t spp, uint32_t firs
  * chunks: the sums then differ from pt_render_into's by the order of fp32 additions
  * only (equal bit for bit when both cut alike, as for small images).  All calls on a
  * GPU share that GPU's area: calls that overlap on one GPU, from any context or
- * stream, race; pt_get_counters after the call reads the area too. */
+ * stream, race; pt_get_counters after the call reads the area too.  A call made while
+ * the context's stream is being captured becomes nodes of the graph (a memset and two
+ * kernels) and leaves no counters: pt_get_counters then fails with PT_E_INVALID. */
 int pt_render_into_static(pt_ctx *ctx, float *accum_device, uint32_t spp, uint32_t first_sample,
                           uint64_t seed, int mode);
 

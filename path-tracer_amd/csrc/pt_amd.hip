@@ -597,16 +597,23 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
     P.stats = reinterpret_cast<unsigned long long *>(ws.queue + 2);
     ctx->last_queue = ws.queue;
 
+    // Under stream capture (the launches become nodes of a HIP graph and run when the graph is
+    // replayed) the timing events are left out: an event recorded into a graph cannot be waited
+    // for or read afterwards, and the counters of such a call do not exist.
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (ctx->stream) HIP_TRY(ctx, hipStreamIsCapturing(ctx->stream, &capture));
+    const bool timed = capture == hipStreamCaptureStatusNone;
+
     HIP_TRY(ctx, hipMemsetAsync(ws.queue, 0, QUEUE_BYTES, ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), lds_bytes, ctx->stream, P);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     const size_t n = (size_t)n_pixels * 3;
     hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks_for((long long)n)), dim3(BLOCK), 0, ctx->stream,
                        ws.slabs, n_chunks, n, accum);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
 
     hipFuncAttributes attr{};
     HIP_TRY(ctx, hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(kernel)));
@@ -615,8 +622,8 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
     ctx->last.vgprs = (uint32_t)attr.numRegs;
     ctx->last.grid_blocks = grid;
     ctx->last.accel = KIND == SCENE_BVH ? PT_ACCEL_BVH : PT_ACCEL_NONE;
-    ctx->last_valid = true;
-    ctx->last_pending = true;
+    ctx->last_valid = timed;
+    ctx->last_pending = timed;
     return PT_OK;
 }
 

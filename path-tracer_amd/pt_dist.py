@@ -41,10 +41,12 @@ def render_share(renderer, accum, total_spp, world, rank, first_sample=0, seed=1
     return count
 
 
-def reduce_image(accum, dst=0, group=None):
-    """Sums the ranks' accumulation buffers onto rank `dst` with one collective."""
+def reduce_image(accum, dst=0, group=None, always=False):
+    """Sums the ranks' accumulation buffers onto rank `dst` with one collective.  A group of one
+    rank has nothing to add and skips the call, unless `always` asks for it (to exercise the
+    backend on a one-GPU box)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or always):
         if accum.is_cuda and dist.get_backend(group) == "gloo":
             # gloo has no reduce for device tensors: stage through the host.  Only
             # rehearsals of the multi-rank path on a box with fewer GPUs than ranks

@@ -67,3 +67,21 @@ def test_bench_launches_its_own_ranks():
     out = run([sys.executable, "bench.py", "--gpus", "2"] + SMALL, env={"PT_BENCH_BACKEND": "gloo"})
     check_contract(out, 2)
     assert "gloo" in out["config"]["parallelism"]
+
+
+def test_bench_makes_an_rccl_process_group_at_one_rank():
+    """PT_BENCH_FORCE_PG=1: the "nccl" (RCCL) process group is initialised at world size 1 and
+    the per-step reduce and the barriers run through it - the code the multi-GPU launch uses,
+    executed once on the one-GPU box."""
+    out = run([sys.executable, "bench.py", "--cpu-spp", "0"] + SMALL, env={"PT_BENCH_FORCE_PG": "1"})
+    check_contract(out, 1)
+    assert out["config"]["process_group"] == "nccl, world 1"
+
+
+def test_bench_rank_failure_exits_non_zero():
+    """A rank that raises must end with a non-zero code at once, so that the launcher tears the
+    other ranks down: here a scene name that does not exist."""
+    p = subprocess.run([sys.executable, "bench.py", "--scene", "no_such_scene", "--cpu-spp", "0"] + SMALL,
+                       cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "Traceback" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]

@@ -85,6 +85,69 @@ def test_static_scratch_limits(ctx, pt):
         ctx.render_into_static(host.ctypes.data, 1, 0, 1, 0)
 
 
+def test_static_scratch_call_leaves_device_memory_as_it_found_it(ctx, pt):
+    """What the entry point's name promises: the device's free memory (hipMemGetInfo) is the same
+    before and after the call - scan, hierarchy and both numeric policies - once a first call has
+    loaded the kernels (the runtime sets up code objects and the private segment the first time a
+    kernel runs; that is the runtime's, once per process, not the call's)."""
+    import torch
+    for name, w, h, spp in (("cornell_2", 320, 200, 6), ("heightfield:12", 160, 120, 4)):
+        sc = pt.builtin_scene(name, w, h)
+        ctx.load(sc)
+        buf = torch.zeros(h, w, 3, dtype=torch.float32, device="cuda:0")
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        try:
+            for mode in (pt.NUM_EXACT, pt.NUM_FAST):
+                ctx.render_into_static(buf.data_ptr(), spp, 0, 1, mode)       # warm-up
+                torch.cuda.synchronize()
+                free_before, _ = torch.cuda.mem_get_info(0)
+                for k in range(3):
+                    ctx.render_into_static(buf.data_ptr(), spp, spp * (k + 1), 1, mode)
+                torch.cuda.synchronize()
+                free_after, _ = torch.cuda.mem_get_info(0)
+                assert free_after == free_before, (name, mode, free_before - free_after)
+        finally:
+            ctx.set_stream(0)
+
+
+def test_static_scratch_call_under_stream_capture(ctx, pt):
+    """The callers the entry point is for: captured into a HIP graph (where an allocation would
+    fail the capture), then replayed twice - each replay renders the image pt_render_into renders."""
+    import torch
+    sc = pt.builtin_scene("cornell_2", 200, 120)
+    ctx.load(sc)
+    spp, seed = 7, 5
+    want = torch.zeros(120, 200, 3, dtype=torch.float32, device="cuda:0")
+    got = torch.zeros_like(want)
+    stream = torch.cuda.Stream()
+    ctx.set_stream(stream.cuda_stream)
+    try:
+        ctx.render_into(want.data_ptr(), spp, 0, seed, 0)
+        ctx.render_into_static(got.data_ptr(), spp, 0, seed, 0)               # warm-up, not captured
+        stream.synchronize()
+        assert torch.equal(got, want)
+        got.zero_()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            ctx.render_into_static(got.data_ptr(), spp, 0, seed, 0)
+        torch.cuda.synchronize()
+        assert not got.any()                       # captured, not run
+        with pytest.raises(pt.PtError):            # a captured call has no counters
+            ctx.counters()
+        for _ in range(2):
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(got, want)
+            got.zero_()
+        # and the context works as before once the capture is over
+        ctx.render_into_static(got.data_ptr(), spp, 0, seed, 0)
+        stream.synchronize()
+        assert torch.equal(got, want) and ctx.counters().samples == 200 * 120 * spp
+    finally:
+        ctx.set_stream(0)
+
+
 def test_static_scratch_symbol_is_exported(pt):
     lib = pt.load()
     assert lib.pt_render_into_static.restype is C.c_int

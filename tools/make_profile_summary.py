@@ -70,8 +70,13 @@ if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
     if avg_ns:
         lines.append("  over the kernel's %.3f ms: %.2f GB/s of 8000 GB/s" % (avg_ns / 1e6, hbm / avg_ns))
     if "--traffic" in sys.argv:
+        sys.path.insert(0, ROOT)
+        from bench import kernel_source_hash
+        # kernel_ms and the hash of the device sources tie the counters to the kernel they were
+        # collected on: bench.py reports them only for that kernel
         rec = {"hbm_bytes_per_launch": hbm, "fetch_size_kib": mean["FETCH_SIZE"],
-               "write_size_kib": mean["WRITE_SIZE"], "kernel": kern, "source": tag + ".txt"}
+               "write_size_kib": mean["WRITE_SIZE"], "kernel": kern, "source": tag + ".txt",
+               "kernel_ms": avg_ns / 1e6 if avg_ns else None, "source_sha1": kernel_source_hash()}
         if "SQ_INSTS_VALU" in mean and "GRBM_GUI_ACTIVE" in mean:
             rec["valu_insts_per_simd_cycle"] = mean["SQ_INSTS_VALU"] / (1024 * mean["GRBM_GUI_ACTIVE"] / 8)
         if "SQ_THREAD_CYCLES_VALU" in mean and "SQ_ACTIVE_INST_VALU" in mean:
