@@ -433,10 +433,13 @@ static inline uint32_t pcg(uint32_t v)
 
 /* The counter-based generator the HIP path uses in place of libc rand() (a design change: the
  * reference's generator is serial global state).  key = pcg(pcg(seed ^ pixel) ^ sample * G),
- * draw i = pcg(key ^ i * G): neither level is additive, so paths whose keys meet or lie close
- * do not replay each other in runs. */
+ * start = pixel * A + sample * B, draw i = pcg(key ^ (start + i * G)): neither level of the key is
+ * additive, so paths whose keys lie close do not replay each other in runs, and the starting
+ * counter keeps two paths whose 32-bit keys meet from drawing the same numbers. */
 #define RNG_STEP 0x9E3779B9u
-typedef struct { uint32_t key, ctr; } rng_t;       /* ctr = RNG_STEP * draws made so far */
+#define RNG_PIXEL_MUL 0x85EBCA6Bu
+#define RNG_SAMPLE_MUL 0xC2B2AE35u
+typedef struct { uint32_t key, ctr; } rng_t;       /* ctr = start + RNG_STEP * draws made so far */
 
 static inline uint32_t seed_mix(uint64_t seed)
 {
@@ -447,7 +450,7 @@ static inline rng_t rng_path(uint32_t smix, uint32_t pixel, uint32_t sample)
 {
     rng_t r;
     r.key = pcg(pcg(smix ^ pixel) ^ (sample * RNG_STEP));
-    r.ctr = 0;
+    r.ctr = pixel * RNG_PIXEL_MUL + sample * RNG_SAMPLE_MUL;
     return r;
 }
 
@@ -491,6 +494,20 @@ static int g_path_cap = 0;
 
 void orc_set_path_cap(int segments) { g_path_cap = segments > 0 ? segments : 0; }
 
+/* 1: russian roulette as the source has it (a survivor's throughput is divided by its survival
+ * probability, main.cpp:104); 0: without that division - a hypothesis about the revision that
+ * rendered the shipped images, for tests/test_reference_images.py to weigh against the others. */
+static int g_rr_compensation = 1;
+
+void orc_set_rr_compensation(int on) { g_rr_compensation = on != 0; }
+
+/* First depth at which russian roulette is played: 5 in the source (main.cpp:97).  A test knob:
+ * with a start beyond every path (and a cap) the estimator has no roulette at all, which is what
+ * the roulette's estimate must equal in the mean. */
+static int g_rr_start = 5;
+
+void orc_set_rr_start(int depth) { g_rr_start = depth >= 0 ? depth : 5; }
+
 /* main.cpp:80-111 */
 static v3 trace_ray(const orc_scene *scene, v3 origin, v3 dir, rand_src *rs,
                     uint64_t *segments, uint64_t *max_depth)
@@ -521,7 +538,7 @@ static v3 trace_ray(const orc_scene *scene, v3 origin, v3 dir, rand_src *rs,
 
             if (g_path_cap && depth + 1 >= g_path_cap)   /* test knob, absent from the reference */
                 break;
-            if (depth < 5)
+            if (depth < g_rr_start)
                 continue;
             if (depth + 1 >= ORC_MAX_DEPTH)   /* safety cap, absent from the reference */
                 break;
@@ -532,7 +549,8 @@ static v3 trace_ray(const orc_scene *scene, v3 origin, v3 dir, rand_src *rs,
             float p = mx < 0.0f ? 0.0f : (0.95f < mx ? 0.95f : mx);
             if (draw(rs) > (double)p)
                 break;
-            throughput = scale(throughput, 1 / p);
+            if (g_rr_compensation)
+                throughput = scale(throughput, 1 / p);
         } else {
             color = add(color, mul(bg, throughput));
             break;

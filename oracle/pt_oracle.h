@@ -139,6 +139,16 @@ float orc_rng_uniform(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t d
  * (tests/test_reference_images.py).  Not thread-safe against a render in progress. */
 void orc_set_path_cap(int segments);
 
+/* Russian roulette of later renders with (1, the default: main.cpp:104) or without (0) the
+ * division of a survivor's throughput by its survival probability.  A test knob, like the cap:
+ * one of the hypotheses tests/test_reference_images.py weighs against the shipped images. */
+void orc_set_rr_compensation(int on);
+
+/* First depth at which later renders play russian roulette (5: main.cpp:97; negative restores
+ * it).  A test knob: beyond every path's length there is no roulette, the estimate the
+ * roulette's own must equal in the mean. */
+void orc_set_rr_start(int depth);
+
 void orc_render(const orc_scene *scene, const orc_camera *cam, uint32_t spp,
                 uint32_t first_sample, uint64_t seed, int threads,
                 float *accum, orc_counters *counters);

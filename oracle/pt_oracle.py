@@ -194,6 +194,16 @@ def set_path_cap(segments):
     lib().orc_set_path_cap(int(segments))
 
 
+def set_rr_compensation(on):
+    """Russian roulette of later renders with (True: the source) or without the 1/p factor."""
+    lib().orc_set_rr_compensation(1 if on else 0)
+
+
+def set_rr_start(depth):
+    """Later renders play russian roulette from this depth on (5: the source; negative restores it)."""
+    lib().orc_set_rr_start(int(depth))
+
+
 def render_libc_rand(scene, spp, seed=1, accum=None):
     if accum is None:
         accum = np.zeros((scene.height, scene.width, 3), dtype=np.float32)

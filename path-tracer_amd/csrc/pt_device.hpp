@@ -100,13 +100,17 @@ struct Num {
 // a pure function of the stream and i.  Values are odd multiples of 2^-24, so
 // they lie strictly inside (0,1).
 //
-// Neither level is additive: the stream's key is pcg(pixel_key ^ sample * G) and draw i is
-// pcg(key ^ i * G), G = 2^32 / golden ratio.  With sums in place of the exclusive-ors, two
-// pixels whose keys lie less than spp apart (some 10^5 pairs in an 800 x 800 image) would trace
-// hundreds of identical paths at shifted sample numbers, and two paths with neighbouring keys
-// would draw each other's numbers a few draws later; as it is, the 32-bit keys of an image's
-// 10^9 paths still meet now and then (the birthday bound), but scattered over all pixel pairs,
-// one path at a time.
+// A stream is named by 64 bits: a key, pcg(pixel_key ^ sample * G), and the counter its draws
+// start from, pixel * A + sample * B (A, B odd); draw i is pcg(key ^ (start + i * G)), G = 2^32 /
+// golden ratio.  Neither level of the key is additive: with sums in place of the exclusive-ors,
+// two pixels whose keys lie less than spp apart (some 10^5 pairs in an 800 x 800 image) would
+// trace hundreds of identical paths at shifted sample numbers, and two paths with neighbouring
+// keys would draw each other's numbers a few draws later.  The starting counter is what keeps two
+// paths whose 32-bit keys meet (the birthday bound: of an image's 10^9 paths some 10^8 pairs,
+// and every key eight times over in a 3840 x 2160 image at 4096 samples per pixel) from drawing
+// the same numbers: their draws coincide only where key ^ counter does, one draw at a time, as
+// the draws of any two paths may.  It costs two integer multiplications per path and no
+// register: the counter is part of the stream's state anyway.
 
 PT_DEV uint32_t pcg(uint32_t v)
 {
@@ -117,16 +121,18 @@ PT_DEV uint32_t pcg(uint32_t v)
 
 constexpr uint32_t RNG_STEP = 0x9E3779B9u;
 
-struct Rng { uint32_t key, ctr; };      // ctr = RNG_STEP * (draws made so far)
+constexpr uint32_t RNG_PIXEL_MUL = 0x85EBCA6Bu, RNG_SAMPLE_MUL = 0xC2B2AE35u;
+
+struct Rng { uint32_t key, ctr; };      // ctr = the stream's start + RNG_STEP * (draws made so far)
 
 // Per-pixel part of the key: computed once per work item.
 PT_DEV uint32_t rng_pixel(uint32_t seed_mix, uint32_t pixel) { return pcg(seed_mix ^ pixel); }
 
-PT_DEV Rng rng_path(uint32_t pixel_key, uint32_t sample)
+PT_DEV Rng rng_path(uint32_t pixel_key, uint32_t pixel, uint32_t sample)
 {
     Rng r;
     r.key = pcg(pixel_key ^ (sample * RNG_STEP));
-    r.ctr = 0;
+    r.ctr = pixel * RNG_PIXEL_MUL + sample * RNG_SAMPLE_MUL;
     return r;
 }
 

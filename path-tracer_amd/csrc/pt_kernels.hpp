@@ -329,7 +329,7 @@ k_rng_uniform(uint32_t seed_mix, const uint32_t *pixel, const uint32_t *sample,
 {
     const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    const Rng r = rng_path(rng_pixel(seed_mix, pixel[i]), sample[i]);
+    const Rng r = rng_path(rng_pixel(seed_mix, pixel[i]), pixel[i], sample[i]);
     out[i] = rng_at(r, draw[i]);
 }
 
@@ -389,9 +389,9 @@ struct PathState {
 // The start of a path: trace_rays' per-pixel set-up, src/main.cpp:120-136.
 // base: pixel_base of the path's pixel (the part of the ray set-up that is the same for every
 // sample of a pixel is formed once per work item).
-PT_DEV void path_begin(PathState &ps, const Camera &cam, uint32_t pixel_key, uint32_t sample, V3 base)
+PT_DEV void path_begin(PathState &ps, const Camera &cam, uint32_t pixel_key, uint32_t pixel, uint32_t sample, V3 base)
 {
-    ps.rng = rng_path(pixel_key, sample);
+    ps.rng = rng_path(pixel_key, pixel, sample);
     const float xu = rng_next(ps.rng), xv = rng_next(ps.rng);
     float xr = 0.0f, xp = 0.0f;
     if (cam.dof_on) { xr = rng_next(ps.rng); xp = rng_next(ps.rng); }
@@ -582,7 +582,7 @@ k_render_mega(RenderParams P)
             }
         }
         if (need_path) {
-            path_begin(ps, P.cam, it.pixel_key, it.s, it.base);
+            path_begin(ps, P.cam, it.pixel_key, it.pixel, it.s, it.base);
             need_path = false;
         }
         const bool ended = path_segment<FAST, KIND, SPHERE_SKIP>(ps, P.scene, shade, lds_shade, P.stats + 1);
@@ -626,7 +626,7 @@ k_render_mega_tiled(RenderParams P)
         }
         if (__syncthreads_count(alive) == 0) break;             // workgroup-uniform
         if (alive && need_path) {
-            path_begin(ps, P.cam, it.pixel_key, it.s, it.base);
+            path_begin(ps, P.cam, it.pixel_key, it.pixel, it.s, it.base);
             need_path = false;
         }
         const V3 o = alive ? ps.o : v3(0, 0, 0), d = alive ? ps.d : v3(0, 0, 1);
@@ -723,7 +723,7 @@ k_render_mega_bvh(RenderParams P)
                 }
             }
             if (waits && alive) {
-                if (need_path) path_begin(ps, P.cam, it.pixel_key, it.s, it.base);
+                if (need_path) path_begin(ps, P.cam, it.pixel_key, it.pixel, it.s, it.base);
                 // the surfaces outside the hierarchy first, then the hierarchy
                 Hit outside;
                 if constexpr (FAST)
@@ -823,7 +823,7 @@ k_wf_generate(WfParams P)
     if (i >= P.n_paths) return;
     const uint32_t s = i / P.n_pixels, pixel = i - s * P.n_pixels;
     PathState ps;
-    path_begin(ps, P.cam, rng_pixel(P.seed_mix, pixel), P.first_sample + s,
+    path_begin(ps, P.cam, rng_pixel(P.seed_mix, pixel), pixel, P.first_sample + s,
                pixel_base(P.cam, (int)(pixel % (uint32_t)P.cam.width), (int)(pixel / (uint32_t)P.cam.width)));
     const uint32_t shard = blockIdx.x % WF_SHARDS, local = blockIdx.x / WF_SHARDS;
     wf_store(P.in, shard * P.shard_cap + local * BLOCK + threadIdx.x, ps, i);

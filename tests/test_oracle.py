@@ -203,3 +203,61 @@ def test_neighbouring_pixel_keys_do_not_share_runs_of_paths(orc):
     for other in (9, 11, 12):
         seq = [orc.rng_uniform(seed, 1234, other, i) for i in range(24)]
         assert len(set(base) & set(seq)) <= 1
+
+
+def test_paths_whose_keys_meet_do_not_draw_the_same_numbers(orc):
+    """A path's stream is named by 64 bits, the key and the counter its draws start from.  Among
+    the 5 million paths of eight samples of an 800 x 800 image some three thousand pairs have the
+    same 32-bit key (the birthday bound); with the counters starting at zero such a pair would
+    draw identical numbers throughout.  They start at pixel * A + sample * B instead."""
+    def pcg(v):
+        v = np.asarray(v, dtype=np.uint64) & 0xFFFFFFFF
+        s = (v * 747796405 + 2891336453) & 0xFFFFFFFF
+        w = (((s >> ((s >> 28) + 4)) ^ s) * 277803737) & 0xFFFFFFFF
+        return ((w >> 22) ^ w) & 0xFFFFFFFF
+
+    seed = 1
+    smix = int(pcg(int(pcg(seed)) ^ 0))
+    pixels = np.arange(800 * 800, dtype=np.uint64)
+    pixel_keys = pcg(smix ^ pixels)
+    samples = np.arange(8, dtype=np.uint64)
+    keys = pcg(pixel_keys[:, None] ^ ((samples[None, :] * 0x9E3779B9) & 0xFFFFFFFF)).ravel()
+    order = np.argsort(keys, kind="stable")
+    same = np.flatnonzero(np.diff(keys[order]) == 0)
+    assert len(same) > 1000
+    for k in same[:60]:
+        a, b = int(order[k]), int(order[k + 1])
+        pa, sa, pb, sb = a // 8, a % 8, b // 8, b % 8
+        assert (pa, sa) != (pb, sb)
+        da = [orc.rng_uniform(seed, pa, sa, i) for i in range(16)]
+        db = [orc.rng_uniform(seed, pb, sb, i) for i in range(16)]
+        assert len(set(da) & set(db)) <= 1, (pa, sa, pb, sb)
+
+
+def test_russian_roulette_is_unbiased(orc):
+    """src/main.cpp:97-104: from depth 5 on a path survives with probability p and a survivor's
+    throughput is divided by p, so the mean image must equal that of the same loop without any
+    roulette (here: paths followed for 48 segments, beyond which cornell_2 holds a millionth of
+    its light).  Held to 4 standard errors of the difference of the image means, estimated from
+    independent halves of each render - a long-path energy bug cannot hide behind a path cap."""
+    sc = orc.builtin_scene("cornell_2", 24, 24)
+    spp = 2048
+
+    def halves(seed0):
+        a, ca = orc.render(sc, spp, seed=seed0, threads=8)
+        b, _ = orc.render(sc, spp, seed=seed0 + 1, threads=8)
+        return a.mean((0, 1)) / spp, b.mean((0, 1)) / spp, ca
+
+    r1, r2, c_rr = halves(11)
+    orc.set_rr_start(1 << 20)
+    orc.set_path_cap(48)
+    try:
+        n1, n2, c_no = halves(21)
+    finally:
+        orc.set_rr_start(-1)
+        orc.set_path_cap(0)
+    assert c_no.segments > 1.5 * c_rr.segments          # the roulette does end paths
+    with_rr, without = (r1 + r2) / 2, (n1 + n2) / 2
+    err = np.sqrt(((r1 - r2) ** 2 + (n1 - n2) ** 2) / 4)     # standard error of the difference of the two means
+    print("with roulette", with_rr, "without", without, "standard error", err)
+    assert np.all(np.abs(with_rr - without) <= 4 * err + 1e-4 * without)
