@@ -10,8 +10,11 @@ author converted them), at the reference's native sizes:
   DOF_on.png               355 x 200   Scenes::dof_demo    (src/scene.hpp:34-57), depth of field on
   DOF_off.png              355 x 200   the same with depth of field switched off (key J)
 
-orange_plane_1600_104s.png and orange_plane_alt_800_55s.png are left out: no depth-of-field
-setting of Scenes::orange_plane reproduces them (they were taken after the camera was moved).
+  orange_plane_alt_800_55s.png  356 x 200  Scenes::orange_plane (src/scene.hpp:73-93), as the source has it
+  orange_plane_1600_104s.png    356 x 200  the same with the lens focused at 3.0 instead of 5 (key K)
+
+(The poses of the last two were found by tests/golden/fit_orange_plane.py; the numbers in the
+file names are samples per pixel and seconds.)
 """
 import os
 
@@ -26,6 +29,8 @@ FILES = {
     "red_corner": "red_corner_800_64s.png",
     "dof_demo_on": "DOF_on.png",
     "dof_demo_off": "DOF_off.png",
+    "orange_plane_alt": "orange_plane_alt_800_55s.png",
+    "orange_plane": "orange_plane_1600_104s.png",
 }
 
 if __name__ == "__main__":

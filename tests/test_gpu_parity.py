@@ -1138,6 +1138,11 @@ def test_soak_of_random_scenes_short():
                        capture_output=True, text=True, timeout=280)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     assert "360000 rays x 3 modes, 0 mismatches" in p.stdout
+    # the margin of the hierarchy's boxes as a number: how much of a box's padding the hits of the
+    # reference's scan needed at most (the tool fails above one half)
+    margins = [l for l in p.stdout.splitlines() if l.startswith("padding of ")]
+    print("\n".join(margins))
+    assert any("triangle boxes" in l for l in margins)
 
 
 def test_soak_of_random_renders_short():

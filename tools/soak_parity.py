@@ -15,10 +15,71 @@ import numpy as np  # noqa: E402
 import pt_amd as pt  # noqa: E402
 import pt_oracle as orc  # noqa: E402
 
+# Constants of the hierarchy's boxes (csrc/pt_bvh.hpp, k_bvh_prepare and bvh_begin; the membership
+# rule is build_hierarchy's in csrc/pt_amd.hip), restated to measure how much of each box's padding
+# the reference's hits actually use.
+BVH_ORIGIN_ROUNDING, BVH_GRAZING, BVH_SPHERE_ROUNDING = 8e-6, 0.05, 4e-6
+
+
+def pad_use(surf, o, d, want):
+    """For every ray whose hit (by the oracle) is a surface the hierarchy holds: how far outside
+    the surface's own bounding box the reported hit point lies, as a fraction of the padding the
+    hierarchy gives that box (for a sphere: padding plus what the ray itself adds).  A hit the
+    scan reports is found through the hierarchy as long as that fraction stays below 1.
+    Returns {kind: (largest fraction, the padding's terms at that ray)}."""
+    idx, _, point = want
+    tri = surf["kind"] == pt.TRIANGLE
+    a, b, c = (surf[k].astype(np.float64) for k in ("a", "b", "c"))
+    centre = np.where(tri[:, None], (a + b + c) / 3.0, a)
+    finite = np.isfinite(centre).all(1)
+    spread = float((centre[finite].max(0) - centre[finite].min(0)).sum())
+    lo = np.where(tri[:, None], np.minimum(np.minimum(a, b), c), a)
+    hi = np.where(tri[:, None], np.maximum(np.maximum(a, b), c), a)
+    size = (hi - lo).sum(1)
+    radius = b[:, 0]
+    reach_c = np.abs(a).sum(1)
+    fits = ~tri & (radius > 0) & (6 * radius <= 0.25 * spread) & (radius >= 1e-3 * spread) & (reach_c <= 1e15)
+    inside = (tri & (size <= 0.1 * spread)) | (fits & (fits.sum() >= 32))
+    extent = np.maximum(np.abs(lo), np.abs(hi))
+    extent[~tri] = np.abs(a[~tri]) + radius[~tri, None]
+    ray_reach = min(4.0 * float(extent.max(0).sum()), 1e30)
+    out = {}
+    hit = (idx >= 0) & np.isfinite(point).all(1) & (np.abs(o).sum(1) <= ray_reach)
+    hit[hit] &= inside[idx[hit]]
+    for name, kind_mask in (("triangle", tri), ("sphere", ~tri)):
+        rays = np.flatnonzero(hit & kind_mask[np.maximum(idx, 0)])
+        if not len(rays):
+            continue
+        i = idx[rays]
+        p = point[rays].astype(np.float64)
+        if name == "triangle":
+            outside = np.maximum(np.maximum(lo[i] - p, p - hi[i]), 0).max(1)
+            l1, l2, l3 = (np.linalg.norm(v, axis=1) for v in (b[i] - a[i], c[i] - a[i], c[i] - b[i]))
+            reach = np.maximum(np.abs(lo[i]), np.abs(hi[i])).max(1)
+            terms = np.stack([1e-3 * size[i], 1e-5 * (1 + reach), np.full(len(i), BVH_ORIGIN_ROUNDING * ray_reach),
+                              BVH_GRAZING * (ray_reach + reach) * l1 * l2 * np.maximum(np.maximum(l1, l2), l3)], 1)
+            labels = ("edge tolerance 1e-3 size", "hit-point rounding", "origin rounding", "grazing")
+        else:
+            outside = np.maximum(np.abs(p - a[i]) - radius[i, None], 0).max(1)
+            reach = np.abs(a[i]).max(1) + radius[i]
+            in_r = radius[inside & ~tri]
+            dd = d[rays].astype(np.float64)
+            off_unit = np.abs((dd * dd).sum(1) - 1.0)
+            far = np.abs(o[rays].astype(np.float64)).sum(1) + reach_c[inside & ~tri].max()
+            terms = np.stack([1e-5 * (1 + reach) + 1e-5 * radius[i], np.full(len(i), BVH_ORIGIN_ROUNDING * ray_reach),
+                              (BVH_SPHERE_ROUNDING + 2 * off_unit) / in_r.min() * far * far], 1)
+            labels = ("hit-point rounding", "origin rounding", "the ray's own allowance for d2")
+        use = outside / terms.sum(1)
+        k = int(use.argmax())
+        out[name] = (float(use[k]), float(outside[k]), dict(zip(labels, terms[k].tolist())), len(rays))
+    return out
+
+
 seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 m = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
 ctx = pt.Context(0)
 bad_total = redone = rays = 0
+worst_use, pad_rays = {}, {}
 t0 = time.time()
 first_seed = int(os.environ.get("SOAK_FIRST_SEED", "0"))
 for seed in range(first_seed, first_seed + seeds):
@@ -91,6 +152,10 @@ for seed in range(first_seed, first_seed + seeds):
         dn = dirs.astype(np.float32)
         d[lo:lo + h] = dn / np.linalg.norm(dn, axis=1, keepdims=True).astype(np.float32)
     want = orc.intersect_rays(osc, o, d)
+    for kind, (use, outside, terms, n_rays) in pad_use(surf, o, d, want).items():
+        if kind not in worst_use or use > worst_use[kind][0]:
+            worst_use[kind] = (use, outside, terms, seed)
+        pad_rays[kind] = pad_rays.get(kind, 0) + n_rays
     for accel in (pt.ACCEL_NONE, pt.ACCEL_BVH, pt.ACCEL_LDS_TILES):
         ctx.set_accel(accel)
         ctx.set_scene(surf, mats, [0, 0, 0])
@@ -115,4 +180,14 @@ for seed in range(first_seed, first_seed + seeds):
     if seed % 10 == 9:
         print("%d seeds, %d rays x 3 modes, %d mismatches, %.0f s" % (seed + 1, rays, bad_total, time.time() - t0), flush=True)
 print("total: %d rays x 3 modes, %d mismatches" % (rays, bad_total))
-sys.exit(1 if bad_total else 0)
+# The margin of the hierarchy's boxes as a number: the largest share of a box's padding that a hit
+# of the reference's scan needed, over every ray that hit a surface inside a hierarchy.
+thin = False
+for kind, (use, outside, terms, seed) in sorted(worst_use.items()):
+    print("padding of %s boxes: the reference's hit points lie at most %.3g outside the surface's own box = %.3f of the "
+          "padding (seed %d, %d rays); its terms there: %s" % (
+              kind, outside, use, seed, pad_rays[kind], ", ".join("%s %.3g" % kv for kv in terms.items())))
+    thin |= use > 0.5
+if thin:
+    print("a hit used more than half of its box's padding: the margin is below 2x")
+sys.exit(1 if bad_total or thin else 0)
