@@ -133,9 +133,11 @@ int main(int argc, char *argv[])
                         r.x, r.y, scene->DOF_on ? 1 : 0, scene->DOF_aperture_size, scene->DOF_focal_length);
         } else if (batch == 0) {
             BUFFER buffer(width, std::vector<vec3>(height, vec3()));
+            // the render step through a pointer of the reference's own type (src/main.cpp:114)
+            void (*const render_step)(Scene &, BUFFER &) = &trace_rays;
             for (int pass = 0; pass < passes; pass++) {
                 scene->camera.update();
-                trace_rays(*scene, buffer);
+                render_step(*scene, buffer);
                 if (TOTAL_SAMPLES % 10 == 0) std::cerr << TOTAL_SAMPLES << std::endl;
             }
             for (const auto &column : buffer)

@@ -316,10 +316,10 @@ inline float gpu_uniform()
 
 }  // namespace pt
 
-// src/main.cpp:114-143.  buffer is indexed buffer[u][v] with u the column;
-// its size gives the image size.  One sample per pixel is added to it and
-// TOTAL_SAMPLES is incremented, exactly the reference's observable effect.
-inline void trace_rays(Scene &scene, BUFFER &buffer, uint32_t spp = 1)
+// src/main.cpp:114-143 for spp samples per pixel in one call.  buffer is indexed buffer[u][v]
+// with u the column; its size gives the image size.  spp samples per pixel are added to it and
+// TOTAL_SAMPLES grows by spp: spp calls of the reference's function.
+inline void trace_rays(Scene &scene, BUFFER &buffer, uint32_t spp)
 {
     if (buffer.empty() || buffer[0].empty() || spp == 0) return;
     const int width = static_cast<int>(buffer.size()), height = static_cast<int>(buffer[0].size());
@@ -343,3 +343,8 @@ inline void trace_rays(Scene &scene, BUFFER &buffer, uint32_t spp = 1)
     }
     TOTAL_SAMPLES += spp;
 }
+
+// The reference's own signature, void(Scene &, BUFFER &) (src/main.cpp:114): one sample per pixel.
+// A function of its own, not a default argument of the one above, so that its address is a
+// void (*)(Scene &, BUFFER &) like the reference's.
+inline void trace_rays(Scene &scene, BUFFER &buffer) { trace_rays(scene, buffer, 1u); }
