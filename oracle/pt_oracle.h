@@ -7,15 +7,18 @@
  *
  * PARITY: the reference (jvgille/Path-Tracer) ships no tests or golden vectors
  * for this path, and it cannot be built in this image (it needs GLM and SDL
- * 1.2, neither of which is present).  What it does ship are five images of its
+ * 1.2, neither of which is present).  What it does ship are seven images of its
  * own renderer (the PNG files under images/): this oracle reproduces them - silhouettes for
  * 99.9 % of the pixels, block means within the images' own noise, mean levels
- * to 0.02-0.3 of a grey level - tests/test_reference_images.py.  That pins
- * camera, scene data, surface tests, samplers, weights and the tone map at
- * image level.  UNPINNED remain: the bit-level operation order of GLM (no
- * image can pin it; restated from GLM's published scalar formulas), and the
- * energy of paths beyond their 7th segment (four of the five images were
- * rendered by a revision that stopped paths there; see orc_set_path_cap).
+ * to 0.02-0.2 of a grey level - tests/test_reference_images.py.  That pins
+ * camera, lens, scene data, surface tests, samplers, weights, russian roulette and
+ * the tone map at image level: the image of the default scene
+ * (orange_plane_alt_800_55s.png) is what the loop of main.cpp:84-109 renders as it
+ * stands, to 0.02 of a grey level; the six others were rendered by a revision
+ * that stopped paths after 7 (8) segments and are reproduced with
+ * orc_set_path_cap.  UNPINNED remain: the bit-level operation order of GLM (no
+ * image can pin it; restated from GLM's published scalar formulas) and 1.3 grey
+ * levels of red in the cornell_2 image that no hypothesis tried explains.
  * Every function below restates the reference's algorithm from its source
  * text, citing file:line.
  *
@@ -132,10 +135,10 @@ float orc_rng_uniform(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t d
  * running sums, row-major, ADDED to.  Pixels are split over `threads` OpenMP
  * threads (1 = serial, as the reference runs).  counters may be NULL. */
 /* Stops every path of later renders after `segments` closest-hit queries (0 = no cap,
- * the default and what the reference's source says, main.cpp:84).  A test knob: the two
- * Cornell-box images the reference ships (images/diffuse.png, images/cornell_800_276s.png)
- * are reproduced to within their own noise with a cap of 7 and not without one, so they
- * were evidently rendered by a revision with a bounded path length
+ * the default and what the reference's source says, main.cpp:84).  A test knob: six of the
+ * seven images the reference ships are reproduced to within their own noise with a cap of 7
+ * (8 for red_corner) and not without one, so they were evidently rendered by a revision with
+ * a bounded path length; the seventh, of the default scene, is reproduced without a cap
  * (tests/test_reference_images.py).  Not thread-safe against a render in progress. */
 void orc_set_path_cap(int segments);
 
