@@ -15,6 +15,9 @@ using namespace ptd;
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
+__device__ unsigned long long g_redone;
+__device__ long long g_ticks[2];        // shader cycles and 100 MHz ticks one wave spent in the loop
+
 template <bool FAST, int N>
 __global__ void __launch_bounds__(256) k_scan(const float *recs, int n_surfaces, int iters, float *out)
 {
@@ -26,20 +29,22 @@ __global__ void __launch_bounds__(256) k_scan(const float *recs, int n_surfaces,
 #pragma unroll
     for (int k = 0; k < M; k++) {
         // rays from near the camera of the scene into the box, a different one per lane and k
-        const float a = (float)((t * N + k) % 9973) * (1.0f / 9973.0f) - 0.5f;
-        const float b = (float)((t * N + k) % 7919) * (1.0f / 7919.0f) - 0.5f;
+        const float a = (float)((t * M + k) % 9973) * (1.0f / 9973.0f) - 0.5f;
+        const float b = (float)((t * M + k) % 7919) * (1.0f / 7919.0f) - 0.5f;
         o[k] = v3(0.01f * a, 0.01f * b, -3.0f);
         d[k] = Num<true>::normalize(v3(a, b, 1.0f));
     }
     float sum = 0.0f;
+    const long long c0 = clock64(), w0 = wall_clock64();
     for (int it = 0; it < iters; it++) {
         Hit h[N > 0 ? N : 1];
         if constexpr (N > 0) {
-            closest_hits<FAST, N>(lds, recs, n_surfaces, o, d, h);
+            if constexpr (FAST) closest_hits_lean<N>(lds, n_surfaces, o, d, h);
+            else closest_hits_exact<N>(lds, as_constant(recs), n_surfaces, o, d, h, &g_redone);
         } else {
             // the one-ray scan with records through the scalar cache (the render kernels' form)
             if constexpr (FAST) h[0] = closest_intersection_lean<false, false>(as_constant(recs), n_surfaces, o[0], d[0]);
-            else h[0] = closest_intersection<false, false>(as_constant(recs), n_surfaces, o[0], d[0]);
+            else h[0] = closest_intersection<false, false>(as_constant(recs), n_surfaces, o[0], d[0], &g_redone);
         }
 #pragma unroll
         for (int k = 0; k < M; k++) {
@@ -50,6 +55,7 @@ __global__ void __launch_bounds__(256) k_scan(const float *recs, int n_surfaces,
         }
     }
     out[t] = sum;
+    if (t == 0) { g_ticks[0] = clock64() - c0; g_ticks[1] = wall_clock64() - w0; }
 }
 
 static void lean_from_geom(const float *g, float *ln)
@@ -94,10 +100,19 @@ static void run(const float *d_geom, const float *d_lean, float *out, int waves_
     const double wave_rays = (double)iters * (N > 0 ? N : 1) * waves_per_simd;          // per SIMD
     const double cycles = ms * 1e-3 * mhz * 1e6 / wave_rays;
     const double flops = 64.0 * (5 * 63 + 3 * 18);
+    unsigned long long redone = 0;
+    CHECK(hipMemcpyFromSymbol(&redone, HIP_SYMBOL(g_redone), sizeof redone));
+    const unsigned long long zero = 0;
+    CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_redone), &zero, sizeof zero));
     hipFuncAttributes attr{};
     CHECK(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_scan<FAST, N>)));
-    printf("%s N=%d waves/SIMD=%d (%3d VGPRs): %7.1f cycles per 64 rays x 8 surfaces = %.3f of the FP32 peak (64 flop/cycle/SIMD)\n",
+    printf("%s N=%d waves/SIMD=%d (%3d VGPRs): %7.1f cycles per 64 rays x 8 surfaces = %.3f of the FP32 peak (64 flop/cycle/SIMD)",
            FAST ? "FAST " : "EXACT", N, waves_per_simd, attr.numRegs, cycles, flops / cycles / 64.0);
+    long long ticks[2] = {0, 1};
+    CHECK(hipMemcpyFromSymbol(ticks, HIP_SYMBOL(g_ticks), sizeof ticks));
+    printf(" [shader clock in the loop %.2f GHz]", (double)ticks[0] / (double)ticks[1] * 0.1);
+    if (!FAST) printf("; %.2e of the rays evaluated directly", (double)redone / (wave_rays * 64.0 * cus * 4 * (20 + iters) / iters));
+    printf("\n");
 }
 
 int main()
