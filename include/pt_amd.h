@@ -158,10 +158,12 @@ int pt_set_scene(pt_ctx *ctx, const pt_surface *surfaces, int32_t n_surfaces,
 int pt_set_accel(pt_ctx *ctx, int accel);
 
 /* Ends every path of later renders after max_segments closest-hit queries
- * (1..PT_MAX_DEPTH; default PT_MAX_DEPTH).  trace_ray's loop (src/main.cpp:84) has no
- * bound; the two Cornell-box images the reference ships (images/diffuse.png,
- * images/cornell_800_276s.png) are reproduced with max_segments = 7, which is what this
- * setting is for besides bounding the cost of a preview. */
+ * (1..PT_MAX_DEPTH; default PT_MAX_DEPTH).  Not the reference's behaviour: trace_ray's loop
+ * (src/main.cpp:84) has no bound, and the default here has none in practice; the image the
+ * reference ships of its default scene (images/orange_plane_alt_800_55s.png) is reproduced
+ * without one.  The setting bounds the cost of a preview, and it is how the tests reproduce
+ * the six other shipped images, which an earlier revision rendered with paths of 7 (8)
+ * segments. */
 int pt_set_max_depth(pt_ctx *ctx, int max_segments);
 
 /* Uploads the camera and DOF state; (re)allocates the accumulation buffer
@@ -290,7 +292,8 @@ int  pt_group_size(pt_group *g);
 /* Context of member i (0 = the device the image is combined on), for pt_get_counters and
  * the parity entry points; do not set its stream, scene or camera directly. */
 pt_ctx *pt_group_context(pt_group *g, int i);
-/* The share of rank `rank` of `n` in samples [first_sample, first_sample + spp_total). */
+/* The share of rank `rank` of `n` in samples [first_sample, first_sample + spp_total); an empty
+ * share (count 0) for n < 1 or a rank outside 0..n-1. */
 void pt_group_share(uint32_t spp_total, int n, int rank, uint32_t first_sample, uint32_t *first, uint32_t *count);
 
 /* pt_set_scene / pt_set_accel / pt_set_max_depth / pt_set_camera / pt_clear on every member
