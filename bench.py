@@ -47,6 +47,10 @@ def parse():
     ap.add_argument("--accel", choices=["auto", "none", "bvh", "tiles"], default="auto",
                     help="pt_set_accel mode: hierarchy by the library's rule, never, whenever possible, "
                          "or the linear scan with its records staged through LDS tiles")
+    ap.add_argument("--partition", choices=["samples", "rows"], default="samples",
+                    help="how N GPUs share a step: every rank its own samples of the whole image (the default), "
+                         "or every rank all samples of its own band of rows (the step is then N x spp samples "
+                         "per pixel on every rank's band, the same work in all)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-spp", type=int, default=32,
                     help="samples per pixel of the CPU baseline's bounded sample (0 = skip)")
@@ -206,8 +210,12 @@ def main():
 
     def step(i):
         # step i renders global samples [i*world*spp, (i+1)*world*spp), split over the ranks
-        pt_dist.render_share(ctx, accum, args.spp * world, world, rank,
-                             first_sample=i * world * args.spp, seed=args.seed, mode=mode)
+        if args.partition == "rows":
+            pt_dist.render_band(ctx, accum, args.spp * world, world, rank,
+                                first_sample=i * world * args.spp, seed=args.seed, mode=mode)
+        else:
+            pt_dist.render_share(ctx, accum, args.spp * world, world, rank,
+                                 first_sample=i * world * args.spp, seed=args.seed, mode=mode)
         pt_dist.reduce_image(accum, dst=0, always=force_pg)    # one RCCL reduce; a no-op without a process group
 
     def fence():
@@ -221,7 +229,7 @@ def main():
     kernel_ms, flops, segments = [], [], []
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if world > 1:
+        if world > 1 or args.partition == "rows":
             accum.zero_()                  # each step reduces one batch
         step(args.warmup + i)
         c = ctx.counters()                 # waits for this step's kernels (HIP events)
@@ -262,7 +270,8 @@ def main():
                            args.scene, width, height, args.spp, args.layout, args.numeric),
                        "scene": args.scene, "width": width, "height": height, "spp_per_gpu": args.spp,
                        "layout": args.layout, "numeric": args.numeric, "accel": args.accel,
-                       "parallelism": "spp-partition x%d + one %s reduce per step" % (
+                       "parallelism": "%s x%d + one %s reduce per step" % (
+                                          "row bands" if args.partition == "rows" else "spp-partition",
                                           world, "RCCL" if backend == "nccl" else backend)
                                       if world > 1 else "single GPU"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS,

@@ -190,6 +190,17 @@ int pt_render(pt_ctx *ctx, uint32_t spp, uint32_t first_sample, uint64_t seed, i
 int pt_render_into(pt_ctx *ctx, float *accum_device, uint32_t spp, uint32_t first_sample,
                    uint64_t seed, int mode);
 
+/* pt_render_into for a band of the image: rows first_row .. first_row + n_rows - 1 (0 = the
+ * top row) receive spp samples per pixel, the rest of accum_device - still the whole image,
+ * height*width*3 floats - is left as it is.  A pixel's random streams depend on its place in
+ * the whole image, so bands rendered by different GPUs (or one after another) make up the
+ * image one call would render, to the order of fp32 additions.  The reference has no
+ * counterpart (its loops run over the whole buffer, src/main.cpp:118-119); this is the other way
+ * to share an image among GPUs besides sharing its samples.  Megakernel only (PT_E_INVALID with
+ * PT_MODE_WAVEFRONT); n_rows = 0 does nothing. */
+int pt_render_rows(pt_ctx *ctx, float *accum_device, int32_t first_row, int32_t n_rows, uint32_t spp,
+                   uint32_t first_sample, uint64_t seed, int mode);
+
 /* pt_render_into for callers that cannot allocate device memory (code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in
  * the reference.  Same arguments and the same image; the megakernel's work queue and

@@ -490,13 +490,18 @@ struct Workspace {
     float *slabs = nullptr;         // fixed area: room for slab_floats partial sums
     size_t slab_floats = 0;
     bool fixed = false;             // false: ctx->d_queue and ctx->d_slabs
+    // the band of image rows to render (pt_render_rows); n_rows = 0: the whole image
+    uint32_t first_row = 0, n_rows = 0;
 };
 
 template <bool FAST, int KIND>
 int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample, uint64_t seed, Workspace ws,
                   bool count_steps)
 {
-    const uint32_t n_pixels = (uint32_t)ctx->cam.width * (uint32_t)ctx->cam.height;
+    const uint32_t width = (uint32_t)ctx->cam.width;
+    const uint32_t n_pixels = ws.n_rows ? ws.n_rows * width : width * (uint32_t)ctx->cam.height;
+    const uint32_t first_pixel = ws.n_rows ? ws.first_row * width : 0u;
+    accum += (size_t)first_pixel * 3;
     size_t lds_bytes = lds_bytes_for(ctx, KIND);
 
     // scenes with a hierarchy have a megakernel of their own
@@ -576,6 +581,7 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
     P.spp = spp;
     P.chunk_len = chunk_len;
     P.n_pixels = n_pixels;
+    P.first_pixel = first_pixel;
     P.n_items = (uint32_t)n_items64;
     // Items a wave takes per atomic on the queue head.  Every wave of the launch adds to that
     // one word, which takes some 140 adds per microsecond; the batch is sized for about 40 at
@@ -785,6 +791,7 @@ int render_dispatch_body(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first
     const bool fast = (mode & PT_NUM_FAST) != 0;
     if (mode & PT_MODE_WAVEFRONT) {
         if (ws.fixed) return fail(ctx, PT_E_INVALID, "the wavefront layout allocates its path state: megakernel only");
+        if (ws.n_rows) return fail(ctx, PT_E_INVALID, "a band of rows is rendered by the megakernel only");
         return with_variant(fast, scene_kind(ctx), [&]<bool FAST, int KIND>() {
             return launch_wavefront<FAST, KIND>(ctx, accum, spp, first_sample, seed);
         });
@@ -1057,6 +1064,22 @@ int pt_render_into(pt_ctx *ctx, float *accum_device, uint32_t spp, uint32_t firs
     if (rc) return rc;
     if ((rc = check_accum_device(ctx, accum_device))) return rc;
     return render_dispatch(ctx, accum_device, spp, first_sample, seed, mode);
+}
+
+int pt_render_rows(pt_ctx *ctx, float *accum_device, int32_t first_row, int32_t n_rows, uint32_t spp,
+                   uint32_t first_sample, uint64_t seed, int mode)
+{
+    int rc = check_ready(ctx, true);
+    if (rc) return rc;
+    if ((rc = check_accum_device(ctx, accum_device))) return rc;
+    if (first_row < 0 || n_rows < 0 || (int64_t)first_row + n_rows > ctx->cam.height)
+        return fail(ctx, PT_E_INVALID, "rows %d..%lld outside an image of %d rows", first_row,
+                    (long long)first_row + n_rows, ctx->cam.height);
+    if (n_rows == 0) return PT_OK;          // an empty share
+    Workspace ws;
+    ws.first_row = (uint32_t)first_row;
+    ws.n_rows = (uint32_t)n_rows;
+    return render_dispatch(ctx, accum_device, spp, first_sample, seed, mode, ws);
 }
 
 int pt_render_into_static(pt_ctx *ctx, float *accum_device, uint32_t spp, uint32_t first_sample,

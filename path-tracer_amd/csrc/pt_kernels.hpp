@@ -77,8 +77,9 @@ struct RenderParams {
     uint32_t first_sample;
     uint32_t spp;
     uint32_t chunk_len;       // samples per work item
-    uint32_t n_pixels;
-    uint32_t n_items;         // n_pixels * ceil(spp / chunk_len); item = chunk * n_pixels + pixel
+    uint32_t n_pixels;        // pixels this launch renders: the whole image, or a band of rows of it
+    uint32_t first_pixel;     // the first of them, in the image's row-major order
+    uint32_t n_items;         // n_pixels * ceil(spp / chunk_len); item = chunk * n_pixels + (pixel - first_pixel)
     float *slabs;             // n_items * 3 partial sums, slab of chunk k at k * n_pixels * 3
     uint32_t pool_batch;      // work items a wave takes from the queue per atomic (POOL_BATCH_MIN..MAX)
     uint32_t *queue_head;     // zeroed before the launch
@@ -514,13 +515,13 @@ struct ItemState {
     V3 sum;
 };
 
-PT_DEV void item_open(ItemState &it, uint32_t item, const Camera &cam, uint32_t n_pixels, uint32_t first_sample,
-                      uint32_t spp, uint32_t chunk_len, uint32_t seed_mix)
+PT_DEV void item_open(ItemState &it, uint32_t item, const Camera &cam, uint32_t n_pixels, uint32_t first_pixel,
+                      uint32_t first_sample, uint32_t spp, uint32_t chunk_len, uint32_t seed_mix)
 {
     it.item = item;
     it.have = true;
     const uint32_t chunk = item / n_pixels;
-    it.pixel = item - chunk * n_pixels;
+    it.pixel = first_pixel + (item - chunk * n_pixels);
     it.base = pixel_base(cam, (int)(it.pixel % (uint32_t)cam.width), (int)(it.pixel / (uint32_t)cam.width));
     it.s = first_sample + chunk * chunk_len;
     const uint32_t last = first_sample + spp;
@@ -578,7 +579,7 @@ k_render_mega(RenderParams P)
             const uint32_t got = pool_take(pool, want, P.queue_head, P.n_items, P.pool_batch);
             if (want) {
                 if (got == NO_ITEM) break;      // queue empty: this lane retires
-                item_open(it, got, P.cam, P.n_pixels, P.first_sample, P.spp, P.chunk_len, P.seed_mix);
+                item_open(it, got, P.cam, P.n_pixels, P.first_pixel, P.first_sample, P.spp, P.chunk_len, P.seed_mix);
             }
         }
         if (need_path) {
@@ -621,7 +622,7 @@ k_render_mega_tiled(RenderParams P)
             const uint32_t got = pool_take(pool, want, P.queue_head, P.n_items, P.pool_batch);
             if (want) {
                 if (got == NO_ITEM) alive = false;
-                else item_open(it, got, P.cam, P.n_pixels, P.first_sample, P.spp, P.chunk_len, P.seed_mix);
+                else item_open(it, got, P.cam, P.n_pixels, P.first_pixel, P.first_sample, P.spp, P.chunk_len, P.seed_mix);
             }
         }
         if (__syncthreads_count(alive) == 0) break;             // workgroup-uniform
@@ -719,7 +720,7 @@ k_render_mega_bvh(RenderParams P)
                 const uint32_t got = pool_take(pool, want, P.queue_head, P.n_items, P.pool_batch);
                 if (want) {
                     if (got == NO_ITEM) alive = false;       // queue empty: this lane retires
-                    else item_open(it, got, P.cam, P.n_pixels, P.first_sample, P.spp, P.chunk_len, P.seed_mix);
+                    else item_open(it, got, P.cam, P.n_pixels, P.first_pixel, P.first_sample, P.spp, P.chunk_len, P.seed_mix);
                 }
             }
             if (waits && alive) {

@@ -36,7 +36,7 @@ SCENE_NAMES = ("dof_demo", "test", "orange_plane", "red_corner", "sunrise",
 ABI_SYMBOLS = (
     "pt_global_error", "pt_create", "pt_destroy", "pt_last_error", "pt_set_stream",
     "pt_set_scene", "pt_set_accel", "pt_set_max_depth", "pt_set_camera", "pt_clear", "pt_render", "pt_render_into",
-    "pt_render_into_static",
+    "pt_render_into_static", "pt_render_rows",
     "pt_read_accum", "pt_map_accum", "pt_write_accum", "pt_tonemap_rgb8", "pt_primary_hits", "pt_intersect_rays",
     "pt_camera_rays", "pt_eval_bsdf", "pt_eval_brdf", "pt_rng_uniform", "pt_get_counters",
     "pt_group_create", "pt_group_destroy", "pt_group_last_error", "pt_group_size", "pt_group_context",
@@ -263,6 +263,12 @@ class Context:
         self._check(self._lib.pt_render_into(self._h, C.c_void_p(device_ptr), C.c_uint32(spp),
                                              C.c_uint32(first_sample), C.c_uint64(seed),
                                              C.c_int(mode)))
+
+    def render_rows(self, device_ptr, first_row, n_rows, spp, first_sample=0, seed=1, mode=0):
+        """render_into for rows first_row .. first_row + n_rows - 1 of the image only."""
+        self._check(self._lib.pt_render_rows(self._h, C.c_void_p(device_ptr), C.c_int32(first_row),
+                                             C.c_int32(n_rows), C.c_uint32(spp), C.c_uint32(first_sample),
+                                             C.c_uint64(seed), C.c_int(mode)))
 
     def render_into_static(self, device_ptr, spp, first_sample=0, seed=1, mode=0):
         """render_into over the library's static device scratch area: allocates nothing."""

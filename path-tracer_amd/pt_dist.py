@@ -1,6 +1,7 @@
 """Multi-GPU render step: one process per GPU, samples-per-pixel partitioned by
-global sample number, images combined with ONE reduce (RCCL over xGMI when the
-process group's backend is "nccl").
+global sample number (or, on request, the image partitioned into bands of rows),
+images combined with ONE reduce (RCCL over xGMI when the process group's backend
+is "nccl").
 
 The random stream of a path depends only on (seed, pixel, global sample
 number), so the union of the ranks' samples is the same set of paths whatever
@@ -39,6 +40,36 @@ def render_share(renderer, accum, total_spp, world, rank, first_sample=0, seed=1
             renderer.set_stream(torch.cuda.current_stream(accum.device).cuda_stream)
         renderer.render_into(accum.data_ptr(), count, first, seed, mode)
     return count
+
+
+def partition_rows(height, world, rank):
+    """Contiguous band of image rows for `rank` of `world`: returns (first_row, n_rows).  The other
+    way to share an image among GPUs: every rank renders all samples of its rows.  Bands differ by
+    at most one row and tile the image; a band may be empty when world > height."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError("rank %d of world %d" % (rank, world))
+    if height < 0:
+        raise ValueError("height must be non-negative")
+    lo = rank * height // world
+    hi = (rank + 1) * height // world
+    return lo, hi - lo
+
+
+def render_band(renderer, accum, spp, world, rank, first_sample=0, seed=1, mode=0):
+    """Adds all `spp` samples of this rank's band of rows into `accum` (the whole image, height x
+    width x 3 float32 on the renderer's device; rows outside the band are left alone, so with
+    buffers that start at zero the same reduce_image combines the bands - adding zeros is exact,
+    and the combined image does not depend on the number of ranks at all).  `renderer` offers
+    render_rows(device_ptr, first_row, n_rows, spp, first_sample, seed, mode), as pt_amd.Context
+    does.  Rows cost what their paths cost, so bands are not as evenly loaded as sample shares:
+    the sample partition (render_share) is the default."""
+    first_row, n_rows = partition_rows(int(accum.shape[0]), world, rank)
+    if n_rows > 0:
+        if getattr(accum, "is_cuda", False) and hasattr(renderer, "set_stream"):
+            import torch
+            renderer.set_stream(torch.cuda.current_stream(accum.device).cuda_stream)
+        renderer.render_rows(accum.data_ptr(), first_row, n_rows, spp, first_sample, seed, mode)
+    return first_row, n_rows
 
 
 def reduce_image(accum, dst=0, group=None, always=False):

@@ -85,3 +85,16 @@ def test_bench_rank_failure_exits_non_zero():
                        cwd=ROOT, capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "Traceback" in p.stderr
     assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_two_ranks_with_row_bands_over_gloo():
+    """--partition rows: every rank renders all the step's samples of its own band of rows."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",
+               "--partition", "rows"] + SMALL, env={"PT_BENCH_BACKEND": "gloo"})
+    check_contract(out, 2)
+    assert "row bands" in out["config"]["parallelism"]

@@ -28,6 +28,20 @@ def test_partition_tiles_the_range(pt):
         pt_dist.partition_samples(8, 2, 2)
 
 
+def test_row_bands_tile_the_image(pt):
+    sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd"))
+    import pt_dist
+    for height in (0, 1, 7, 200, 2160):
+        for world in (1, 2, 3, 8):
+            bands = [pt_dist.partition_rows(height, world, r) for r in range(world)]
+            assert bands[0][0] == 0 and sum(n for _, n in bands) == height
+            for (f0, n0), (f1, _) in zip(bands, bands[1:]):
+                assert f0 + n0 == f1
+            assert max(n for _, n in bands) - min(n for _, n in bands) <= 1
+    with pytest.raises(ValueError):
+        pt_dist.partition_rows(8, 2, 2)
+
+
 class OracleRenderer:
     """render_into on a CPU tensor, backed by the oracle (test stand-in for a GPU context)."""
 
@@ -38,6 +52,12 @@ class OracleRenderer:
         t = self.tensors[ptr]
         acc = t.numpy()
         self.orc.render(self.scene, spp, first_sample=first_sample, seed=seed, threads=2, accum=acc)
+
+    def render_rows(self, ptr, first_row, n_rows, spp, first_sample, seed, mode):
+        # the oracle renders whole images: the band is cut out of one (a stand-in, as above)
+        acc = self.tensors[ptr].numpy()
+        whole, _ = self.orc.render(self.scene, spp, first_sample=first_sample, seed=seed, threads=2)
+        acc[first_row:first_row + n_rows] += whole[first_row:first_row + n_rows]
 
     def write_accum_device(self, ptr, total_samples):
         self.adopted = (self.tensors[ptr].numpy().copy(), total_samples)
@@ -66,6 +86,45 @@ def _worker(rank, world, port, out_path):
         np.save(out_path, accum.numpy())
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _band_worker(rank, world, port, out_path):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd"))
+    import pt_dist
+    import pt_oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene = pt_oracle.builtin_scene("cornell_2", 36, 25)
+    accum = torch.zeros(25, 36, 3, dtype=torch.float32)
+    r = OracleRenderer(pt_oracle, scene, {accum.data_ptr(): accum})
+    band = pt_dist.render_band(r, accum, spp=5, world=world, rank=rank, first_sample=2, seed=4)
+    assert band == ((0, 12) if rank == 0 else (12, 13))
+    outside = accum.numpy()[12:] if rank == 0 else accum.numpy()[:12]
+    assert not outside.any()
+    pt_dist.reduce_image(accum, dst=0)
+    if rank == 0:
+        np.save(out_path, accum.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_with_row_bands_make_the_single_rank_image_exactly(orc, tmp_path):
+    """The other partition: every rank renders all samples of its own band of rows.  The bands
+    are disjoint and the rest of each rank's buffer is zero, so the reduce adds zeros: the
+    combined image is the one-rank image bit for bit, whatever the number of ranks."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "bands.npy")
+    mp.spawn(_band_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    want, _ = orc.render(orc.builtin_scene("cornell_2", 36, 25), 5, first_sample=2, seed=4, threads=2)
+    assert np.array_equal(got, want) and got.sum() > 0
 
 
 def test_two_ranks_reduce_to_the_single_rank_image(orc, tmp_path):
