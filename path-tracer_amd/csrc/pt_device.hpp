@@ -948,12 +948,14 @@ PT_DEV V3 sample_glass(V3 normal, V3 incident, float xi, bool mirror = false)
 {
     using N = Num<FAST>;
     float n1 = 1.0f, n2 = 1.5f;
+    float n = 1.0f / 1.5f;        // n1 / n2: one constant per side (a quotient of the two selected
+                                  // values would be a division sequence per lane)
     if (!(N::dot(normal, incident) < 0.0f)) {
         normal = -normal;
         n1 = 1.5f;
         n2 = 1.0f;
+        n = 1.5f / 1.0f;
     }
-    const float n = n1 / n2;      // both branches fold to constants
     const float cosI = -N::dot(normal, incident);
     const float sin2T = n * n * (1.0f - cosI * cosI);
     const float cosT = N::sqrt(1.0f - sin2T);     // NaN under total internal reflection

@@ -390,9 +390,9 @@ struct PathState {
 // The start of a path: trace_rays' per-pixel set-up, src/main.cpp:120-136.
 // base: pixel_base of the path's pixel (the part of the ray set-up that is the same for every
 // sample of a pixel is formed once per work item).
-PT_DEV void path_begin(PathState &ps, const Camera &cam, uint32_t pixel_key, uint32_t pixel, uint32_t sample, V3 base)
+PT_DEV void path_begin(PathState &ps, const Camera &cam, Rng stream, V3 base)
 {
-    ps.rng = rng_path(pixel_key, pixel, sample);
+    ps.rng = stream;
     const float xu = rng_next(ps.rng), xv = rng_next(ps.rng);
     float xr = 0.0f, xp = 0.0f;
     if (cam.dof_on) { xr = rng_next(ps.rng); xp = rng_next(ps.rng); }
@@ -510,10 +510,32 @@ PT_DEV uint32_t pool_take(WorkPool &pool, bool want, uint32_t *queue_head, uint3
 // What a lane keeps about its current work item (pixel, chunk of samples).
 struct ItemState {
     bool have;
-    uint32_t item, pixel, pixel_key, s, s_end;
+    uint32_t item, pixel_key;
+    uint32_t left;      // samples of the item not yet started
+    // the next sample's terms of rng_path, kept by addition from sample to sample (the same
+    // integers modulo 2^32 as its multiplications: a 32-bit multiply takes two issue slots)
+    uint32_t key_term;  // sample * RNG_STEP
+    uint32_t ctr;       // pixel * RNG_PIXEL_MUL + sample * RNG_SAMPLE_MUL
     V3 base;            // pixel_base of the item's pixel
     V3 sum;
 };
+
+// The random stream of the item's next sample (rng_path of the pixel and that sample).
+PT_DEV Rng item_stream(const ItemState &it)
+{
+    Rng r;
+    r.key = pcg(it.pixel_key ^ it.key_term);
+    r.ctr = it.ctr;
+    return r;
+}
+
+// One sample of the item has been started and finished.
+PT_DEV void item_next_sample(ItemState &it)
+{
+    it.left--;
+    it.key_term += RNG_STEP;
+    it.ctr += RNG_SAMPLE_MUL;
+}
 
 PT_DEV void item_open(ItemState &it, uint32_t item, const Camera &cam, uint32_t n_pixels, uint32_t first_pixel,
                       uint32_t first_sample, uint32_t spp, uint32_t chunk_len, uint32_t seed_mix)
@@ -521,13 +543,14 @@ PT_DEV void item_open(ItemState &it, uint32_t item, const Camera &cam, uint32_t 
     it.item = item;
     it.have = true;
     const uint32_t chunk = item / n_pixels;
-    it.pixel = first_pixel + (item - chunk * n_pixels);
-    it.base = pixel_base(cam, (int)(it.pixel % (uint32_t)cam.width), (int)(it.pixel / (uint32_t)cam.width));
-    it.s = first_sample + chunk * chunk_len;
-    const uint32_t last = first_sample + spp;
-    it.s_end = it.s + chunk_len < last ? it.s + chunk_len : last;
+    const uint32_t pixel = first_pixel + (item - chunk * n_pixels);
+    it.base = pixel_base(cam, (int)(pixel % (uint32_t)cam.width), (int)(pixel / (uint32_t)cam.width));
+    const uint32_t s = first_sample + chunk * chunk_len, last = first_sample + spp;
+    it.left = (s + chunk_len < last ? s + chunk_len : last) - s;
+    it.key_term = s * RNG_STEP;
+    it.ctr = pixel * RNG_PIXEL_MUL + s * RNG_SAMPLE_MUL;
     it.sum = v3(0, 0, 0);
-    it.pixel_key = rng_pixel(seed_mix, it.pixel);
+    it.pixel_key = rng_pixel(seed_mix, pixel);
 }
 
 PT_DEV void item_close(ItemState &it, float *slabs)
@@ -573,7 +596,7 @@ k_render_mega(RenderParams P)
     unsigned long long n_seg = 0;
 
     for (;;) {
-        const bool want = need_path && it.s == it.s_end;
+        const bool want = need_path && it.left == 0;
         if (__any(want)) {                      // wave-uniform: every live lane enters
             if (want && it.have) item_close(it, P.slabs);
             const uint32_t got = pool_take(pool, want, P.queue_head, P.n_items, P.pool_batch);
@@ -583,14 +606,14 @@ k_render_mega(RenderParams P)
             }
         }
         if (need_path) {
-            path_begin(ps, P.cam, it.pixel_key, it.pixel, it.s, it.base);
+            path_begin(ps, P.cam, item_stream(it), it.base);
             need_path = false;
         }
         const bool ended = path_segment<FAST, KIND, SPHERE_SKIP>(ps, P.scene, shade, lds_shade, P.stats + 1);
         n_seg++;
         if (ended) {
             it.sum = it.sum + ps.col;           // buffer[u][v] += color, main.cpp:139
-            it.s++;
+            item_next_sample(it);
             need_path = true;
         }
     }
@@ -616,7 +639,7 @@ k_render_mega_tiled(RenderParams P)
     unsigned long long n_seg = 0;
 
     for (;;) {
-        const bool want = alive && need_path && it.s == it.s_end;
+        const bool want = alive && need_path && it.left == 0;
         if (__any(want)) {                      // wave-uniform: every lane of the wave enters
             if (want && it.have) item_close(it, P.slabs);
             const uint32_t got = pool_take(pool, want, P.queue_head, P.n_items, P.pool_batch);
@@ -627,7 +650,7 @@ k_render_mega_tiled(RenderParams P)
         }
         if (__syncthreads_count(alive) == 0) break;             // workgroup-uniform
         if (alive && need_path) {
-            path_begin(ps, P.cam, it.pixel_key, it.pixel, it.s, it.base);
+            path_begin(ps, P.cam, item_stream(it), it.base);
             need_path = false;
         }
         const V3 o = alive ? ps.o : v3(0, 0, 0), d = alive ? ps.d : v3(0, 0, 1);
@@ -636,7 +659,7 @@ k_render_mega_tiled(RenderParams P)
             n_seg++;
             if (shade_hit<FAST>(ps, P.scene, shade, h)) {
                 it.sum = it.sum + ps.col;           // buffer[u][v] += color, main.cpp:139
-                it.s++;
+                item_next_sample(it);
                 need_path = true;
             }
         }
@@ -708,13 +731,13 @@ k_render_mega_bvh(RenderParams P)
                     if (h.idx < 0) h.dist = 0.0f;
                     if (shade_hit<FAST>(ps, P.scene, shade, h)) {
                         it.sum = it.sum + ps.col;            // buffer[u][v] += color, main.cpp:139
-                        it.s++;
+                        item_next_sample(it);
                         need_path = true;
                     }
                     have_hit = false;
                 }
             }
-            const bool want = need_path && it.s == it.s_end;
+            const bool want = need_path && it.left == 0;
             if (__any(want)) {
                 if (want && it.have) item_close(it, P.slabs);
                 const uint32_t got = pool_take(pool, want, P.queue_head, P.n_items, P.pool_batch);
@@ -724,7 +747,7 @@ k_render_mega_bvh(RenderParams P)
                 }
             }
             if (waits && alive) {
-                if (need_path) path_begin(ps, P.cam, it.pixel_key, it.pixel, it.s, it.base);
+                if (need_path) path_begin(ps, P.cam, item_stream(it), it.base);
                 // the surfaces outside the hierarchy first, then the hierarchy
                 Hit outside;
                 if constexpr (FAST)
@@ -824,7 +847,7 @@ k_wf_generate(WfParams P)
     if (i >= P.n_paths) return;
     const uint32_t s = i / P.n_pixels, pixel = i - s * P.n_pixels;
     PathState ps;
-    path_begin(ps, P.cam, rng_pixel(P.seed_mix, pixel), pixel, P.first_sample + s,
+    path_begin(ps, P.cam, rng_path(rng_pixel(P.seed_mix, pixel), pixel, P.first_sample + s),
                pixel_base(P.cam, (int)(pixel % (uint32_t)P.cam.width), (int)(pixel / (uint32_t)P.cam.width)));
     const uint32_t shard = blockIdx.x % WF_SHARDS, local = blockIdx.x / WF_SHARDS;
     wf_store(P.in, shard * P.shard_cap + local * BLOCK + threadIdx.x, ps, i);
