@@ -444,13 +444,13 @@ int with_variant(bool fast, int kind, F &&f)
 }
 
 // Rays per lane of a closest-hit query (k_primary_hits_multi, k_intersect_rays_multi), or 0 for
-// the one-ray kernels.  The N-ray kernels are the FAST policy's (measured on 16.8 M camera rays of
-// cornell_2: 0.115 ms with one ray per lane, 0.103 / 0.097 / 0.094 with 2 / 4 / 8); the EXACT scan
-// compiles to more instructions per ray in that form and keeps the one-ray kernels (0.191 against
-// 0.193 / 0.185 / 0.214 ms), as do scenes with a hierarchy, scenes whose records do not fit the
-// kernels' LDS copy, and the LDS-tiled scan.  More rays per lane mean fewer workgroups, so small
-// queries take fewer.  PT_QUERY_RAYS (0, 1, 2, 4, 8) overrides the choice, for either policy:
-// for measurements and for the parity tests of every form.
+// the one-ray kernels.  Measured on 16.8 M camera rays of cornell_2, ms with one ray per lane
+// through the scalar cache / 2 / 4 / 8 rays per lane: FAST 0.115 / 0.103 / 0.097 / 0.094; EXACT
+// 0.189 / 0.186 / 0.176 / 0.186 (124 registers at 8), and 0.350 / 0.340 / 0.320 / 0.343 on the 16
+// surfaces of cornell.  Scenes with a hierarchy, scenes whose records do not fit the kernels' LDS
+// copy, and the LDS-tiled scan keep the one-ray kernels.  More rays per lane mean fewer
+// workgroups, so small queries take fewer.  PT_QUERY_RAYS (0, 1, 2, 4, 8) overrides the choice,
+// for either policy: for measurements and for the parity tests of every form.
 int query_rays_per_lane(const pt_ctx *ctx, long long n_rays, bool fast)
 {
     if (ctx->accel == PT_ACCEL_LDS_TILES || ctx->n_bvh > 0 || ctx->n_surfaces < 1 ||
@@ -460,9 +460,9 @@ int query_rays_per_lane(const pt_ctx *ctx, long long n_rays, bool fast)
         const int v = atoi(e);
         if (v == 0 || v == 1 || v == 2 || v == 4 || v == 8) return v;
     }
-    if (!fast) return 0;
     // rays per lane if every CU had one workgroup
     const long long per_lane = n_rays / ((long long)std::max(ctx->num_cus, 1) * BLOCK);
+    if (!fast) return per_lane >= 32 ? 4 : 0;
     if (per_lane >= 64) return 8;
     if (per_lane >= 32) return 4;
     if (per_lane >= 16) return 2;

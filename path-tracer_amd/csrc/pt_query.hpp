@@ -52,11 +52,11 @@ PT_DEV void closest_hits_exact(const float *recs, cfloat_p geom, int n_surfaces,
         if (rec.kind == GEOM_TRIANGLE) {                         // wave-uniform
             rec.q2 = p[2];
 #pragma unroll
-            for (int k = 0; k < N; k++) scan_surface<false, false, GEOM_TRIANGLE>(st[k], i, rec, o[k], d[k]);
+            for (int k = 0; k < N; k++) scan_surface<false, false, GEOM_TRIANGLE, true>(st[k], i, rec, o[k], d[k]);
         } else {
             rec.q2 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int k = 0; k < N; k++) scan_surface<false, false, GEOM_SPHERE>(st[k], i, rec, o[k], d[k]);
+            for (int k = 0; k < N; k++) scan_surface<false, false, GEOM_SPHERE, true>(st[k], i, rec, o[k], d[k]);
         }
     }
 #pragma unroll
