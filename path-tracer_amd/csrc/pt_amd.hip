@@ -934,7 +934,7 @@ static int set_scene_body(pt_ctx *ctx, const pt_surface *surfaces, int32_t n_sur
             return fail(ctx, PT_E_INVALID, "surface %d has unknown kind %d", i, kind);
         }
         const int32_t flags = m.type | (kind << 8);
-        memcpy(sh + 0, m.color, 12);
+        for (int k = 0; k < 3; k++) sh[k] = m.type == PT_DIFFUSE ? m.color[k] * 2.0f : m.color[k];
         memcpy(sh + 3, &flags, 4);
         memcpy(sh + 4, m.emittance, 12);
     }

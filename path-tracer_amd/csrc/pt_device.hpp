@@ -172,7 +172,8 @@ constexpr int GEOM_TRIANGLE = 0, GEOM_SPHERE = 1;
 constexpr float GEOM_DIRECT_EDGE_PRODUCT = 1e18f;     // |e1|max * |e2|max above this
 
 // Shading record, 12 floats per surface, read with per-lane indices.
-//  [0..2] color  [3] type | kind<<8  [4..6] emittance  [8..10] triangle normal | sphere position
+//  [0..2] color (diffuse: 2 * color, what Material::brdf multiplies by)  [3] type | kind<<8
+//  [4..6] emittance  [8..10] triangle normal | sphere position
 constexpr int SHADE_STRIDE = 12;
 
 struct Camera {
@@ -630,19 +631,18 @@ PT_DEV void scan_surface(Scan &st, int i, const GeomRec &rec, V3 o, V3 d)
             acc = ~rej;
             mode = near ? 1 : 2;
         } else {
+            // The near root unless it surely lies behind the ray's start, else the far one; the
+            // chosen root surely beyond the start: a hit, surely behind it: none (only the far
+            // root can be), in between: undecided.
             const float e1 = SPH_DIST_ERR * (thc + __builtin_fabsf(t1));
-            const float e2 = SPH_DIST_ERR * (thc + __builtin_fabsf(t2));
-            const float lo1 = t1 - e1, hi1 = t1 + e1, lo2 = t2 - e2, hi2 = t2 + e2;
-            // (compares that start a mask of their own: the literal form needs a scalar move
-            // each, measured no better than the compiler's scalar-register operands)
-            const bool near_ok_lane = lo1 > BAND_T_ACC;
-            const Mask near_ok = PT_B(near_ok_lane), near_bad = PT_B(hi1 < BAND_T_REJ);
-            const Mask far_ok = PT_B(lo2 > BAND_T_ACC), far_bad = PT_B(hi2 < BAND_T_REJ);
-            acc = pre_ok & (near_ok | (near_bad & far_ok));
-            rej = ~pre_ok | (near_bad & far_bad);
-            c_lo = near_ok_lane ? lo1 : lo2;
-            c_hi = near_ok_lane ? hi1 : hi2;
-            mode = near_ok_lane ? 1 : 2;
+            const bool far_lane = t1 + e1 < BAND_T_REJ;
+            const float t = far_lane ? t2 : t1;
+            const float e = SPH_DIST_ERR * (thc + __builtin_fabsf(t));
+            c_lo = t - e;
+            c_hi = t + e;
+            acc = and_gt<f32_bits(BAND_T_ACC)>(pre_ok, c_lo);
+            rej = or_lt<f32_bits(BAND_T_REJ)>(~pre_ok, c_hi);
+            mode = far_lane ? 2 : 1;
         }
         a = tca;
         b = arg;
@@ -961,16 +961,18 @@ template <bool FAST>
 PT_DEV V3 sample_glass(V3 normal, V3 incident, float xi, bool mirror = false)
 {
     using N = Num<FAST>;
-    float n1 = 1.0f, n2 = 1.5f;
-    float n = 1.0f / 1.5f;        // n1 / n2: one constant per side (a quotient of the two selected
-                                  // values would be a division sequence per lane)
-    if (!(N::dot(normal, incident) < 0.0f)) {
-        normal = -normal;
-        n1 = 1.5f;
-        n2 = 1.0f;
-        n = 1.5f / 1.0f;
-    }
-    const float cosI = -N::dot(normal, incident);
+    // The reference turns the normal against the ray when the ray arrives from inside
+    // (material.hpp:38-44) and goes on with the turned normal n' = side * n.  Both directions it
+    // can return are incident (times a scalar) plus a multiple of n': the side goes into that
+    // multiple, k * n' = (side * k) * n, an exact change of sign, and the normal stays as it is.
+    // cosI = -dot(n', i) = |dot(n, i)| on either side.
+    const float ni = N::dot(normal, incident);
+    const bool outside = ni < 0.0f;
+    const float n1 = outside ? 1.0f : 1.5f, n2 = outside ? 1.5f : 1.0f;
+    // n1 / n2: one constant per side (a quotient of the two selected values would be a division
+    // sequence per lane)
+    const float n = outside ? 1.0f / 1.5f : 1.5f / 1.0f;
+    const float cosI = outside ? -ni : ni;
     const float sin2T = n * n * (1.0f - cosI * cosI);
     const float cosT = N::sqrt(1.0f - sin2T);     // NaN under total internal reflection
     float reflectance;
@@ -983,12 +985,14 @@ PT_DEV V3 sample_glass(V3 normal, V3 incident, float xi, bool mirror = false)
     }
     if (mirror | (xi < reflectance)) {
         const float k = 2.0f * cosI;
-        return v3(N::mad(k, normal.x, incident.x), N::mad(k, normal.y, incident.y),
-                  N::mad(k, normal.z, incident.z));
+        const float ks = outside ? k : -k;
+        return v3(N::mad(ks, normal.x, incident.x), N::mad(ks, normal.y, incident.y),
+                  N::mad(ks, normal.z, incident.z));
     }
     const float k = n * cosI - cosT;
-    return v3(N::mad(k, normal.x, n * incident.x), N::mad(k, normal.y, n * incident.y),
-              N::mad(k, normal.z, n * incident.z));
+    const float ks = outside ? k : -k;
+    return v3(N::mad(ks, normal.x, n * incident.x), N::mad(ks, normal.y, n * incident.y),
+              N::mad(ks, normal.z, n * incident.z));
 }
 
 // Material::sample_pdf, src/material.hpp:78-87

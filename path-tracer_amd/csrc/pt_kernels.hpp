@@ -443,15 +443,21 @@ PT_DEV bool shade_hit(PathState &ps, const SceneView &sc, const float *shade, co
     ps.o = point;
     ps.col = v3(S::mad(r1.x, ps.thr.x, ps.col.x), S::mad(r1.y, ps.thr.y, ps.col.y),
                 S::mad(r1.z, ps.thr.z, ps.col.z));             // emission at every hit, main.cpp:92
-    ps.thr = ps.thr * brdf<true>(type, v3(r0.x, r0.y, r0.z), normal, new_dir);
+    // Material::brdf, material.hpp:89-96: the record holds 2 * color for a diffuse surface (an exact
+    // doubling, done once per scene), color otherwise
+    V3 f = v3(r0.x, r0.y, r0.z);
+    if (type == 0) f = f * S::dot(new_dir, normal);
+    ps.thr = ps.thr * f;
     ps.d = new_dir;
     bool ended = false;
     if (ps.depth + 1 >= sc.max_depth) {             // the cap on path length (the reference has none)
         ended = true;
     } else if (ps.depth >= 5) {                     // russian roulette, main.cpp:97-104
-        float m = ps.thr.y < ps.thr.z ? ps.thr.z : ps.thr.y;
-        m = ps.thr.x < m ? m : ps.thr.x;
-        const float p = m < 0.0f ? 0.0f : (0.95f < m ? 0.95f : m);
+        // clamp(max(throughput), 0, 0.95): one maximum of three, then the two bounds (0.95 as a
+        // literal; compares and selects, as the reference's std::max and std::clamp read, are eight)
+        float p;
+        asm("v_max3_f32 %0, %1, %2, %3\n\tv_min_f32 %0, 0x3f733333, %0\n\tv_max_f32 %0, 0, %0"
+            : "=&v"(p) : "v"(ps.thr.x), "v"(ps.thr.y), "v"(ps.thr.z));
         if (rng_next(ps.rng) > p) ended = true;
         else ps.thr = ps.thr * S::div(1.0f, p);
     }
