@@ -21,8 +21,8 @@ FLOPS = RAYS * (5 * 63 + 3 * 18)          # cornell_2: 5 triangles, 3 spheres
 src, tag = sys.argv[1], sys.argv[2]
 lines = ["rocprofv3 summary '%s' (tools/profile_primary.sh: python3 tools/primary_hits_run.py cornell_2 4096," % tag,
          "k_primary_hits over the 16 777 216 camera rays of a 4096 x 4096 image of cornell_2 (5 triangles + 3 spheres),",
-         "3 launches per numeric policy; EXACT: one ray per lane, records through the scalar cache; FAST: N rays per",
-         "lane, records broadcast from LDS into vector registers)", ""]
+         "3 launches per numeric policy, each with the rays per lane the library chooses for a query of this size (N rays per",
+         "lane: records broadcast from LDS into vector registers))", ""]
 
 
 def newest(pattern):
