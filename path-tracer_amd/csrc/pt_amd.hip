@@ -65,6 +65,16 @@ bool extreme_triangle(const pt_surface &s)
     return !(m1 * m2 <= GEOM_DIRECT_EDGE_PRODUCT);      // also when not a number
 }
 
+// The constants of the kernels' fast_div for the divisor d (1 <= d < 2^31).
+FastDiv fast_div_by(uint32_t d)
+{
+    uint32_t s = 0;
+    while ((1ull << s) < d) s++;
+    const unsigned long long two = 1ull << (31 + s);
+    const unsigned long long m = (two + d - 1) / d;          // <= 2^32; exactly 2^31 for a power of two
+    return FastDiv{(uint32_t)std::min<unsigned long long>(m, 0xFFFFFFFFull), s > 0 ? s - 1 : 0, d};
+}
+
 uint32_t host_pcg(uint32_t v)
 {
     uint32_t s = v * 747796405u + 2891336453u;
@@ -554,8 +564,9 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
     const uint32_t chunk_len = (spp + n_chunks - 1) / n_chunks;
     n_chunks = (spp + chunk_len - 1) / chunk_len;
     const uint64_t n_items64 = (uint64_t)n_pixels * n_chunks;
-    if (n_items64 >= 0xF0000000ull)
-        return fail(ctx, PT_E_LIMIT, "%llu work items exceed the 32-bit queue", (unsigned long long)n_items64);
+    // (below 2^31: the queue counts in 32 bits, and the kernels divide item and pixel numbers by fast_div)
+    if (n_items64 >= 0x80000000ull)
+        return fail(ctx, PT_E_LIMIT, "%llu work items exceed the queue's 2^31", (unsigned long long)n_items64);
 
     const size_t need = (size_t)n_items64 * 3;
     if (ws.fixed) {
@@ -583,6 +594,8 @@ int launch_render(pt_ctx *ctx, float *accum, uint32_t spp, uint32_t first_sample
     P.n_pixels = n_pixels;
     P.first_pixel = first_pixel;
     P.n_items = (uint32_t)n_items64;
+    P.by_pixels = fast_div_by(n_pixels);
+    P.by_width = fast_div_by(width);
     // Items a wave takes per atomic on the queue head.  Every wave of the launch adds to that
     // one word, which takes some 140 adds per microsecond; the batch is sized for about 40 at
     // the rate this scene is expected to consume samples (samples per microsecond, from what

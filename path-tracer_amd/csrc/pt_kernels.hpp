@@ -70,6 +70,18 @@ PT_DEV Hit closest_hit(const SceneView &sc, V3 o, V3 d, float *lds, unsigned lon
     }
 }
 
+// Division of a number below 2^31 by a constant d >= 1 as a multiplication's high half and a shift
+// (the host's fast_div): two instructions where the general 32-bit division is sixteen.
+// With s = ceil(log2 d) and m = ceil(2^(31+s) / d) <= 2^32 the error m d - 2^(31+s) is below
+// d <= 2^s, so n m / 2^(31+s) has the integer part of n / d for every n < 2^31.  (d = 1: s = 0, and
+// the quotient is n itself; a power of two makes m = 2^31.)
+struct FastDiv { uint32_t m, shift, d; };
+
+PT_DEV uint32_t fast_div(uint32_t n, FastDiv f)
+{
+    return f.d == 1u ? n : __umulhi(n, f.m) >> f.shift;
+}
+
 struct RenderParams {
     Camera cam;
     SceneView scene;
@@ -80,6 +92,7 @@ struct RenderParams {
     uint32_t n_pixels;        // pixels this launch renders: the whole image, or a band of rows of it
     uint32_t first_pixel;     // the first of them, in the image's row-major order
     uint32_t n_items;         // n_pixels * ceil(spp / chunk_len); item = chunk * n_pixels + (pixel - first_pixel)
+    FastDiv by_pixels, by_width;   // division by n_pixels and by the image's width (item_open)
     float *slabs;             // n_items * 3 partial sums, slab of chunk k at k * n_pixels * 3
     uint32_t pool_batch;      // work items a wave takes from the queue per atomic (POOL_BATCH_MIN..MAX)
     uint32_t *queue_head;     // zeroed before the launch
@@ -543,14 +556,17 @@ PT_DEV void item_next_sample(ItemState &it)
     it.ctr += RNG_SAMPLE_MUL;
 }
 
-PT_DEV void item_open(ItemState &it, uint32_t item, const Camera &cam, uint32_t n_pixels, uint32_t first_pixel,
-                      uint32_t first_sample, uint32_t spp, uint32_t chunk_len, uint32_t seed_mix)
+PT_DEV void item_open(ItemState &it, uint32_t item, const RenderParams &P)
 {
+    const Camera &cam = P.cam;
+    const uint32_t n_pixels = P.n_pixels, first_pixel = P.first_pixel, first_sample = P.first_sample, spp = P.spp,
+                   chunk_len = P.chunk_len, seed_mix = P.seed_mix;
     it.item = item;
     it.have = true;
-    const uint32_t chunk = item / n_pixels;
+    const uint32_t chunk = fast_div(item, P.by_pixels);
     const uint32_t pixel = first_pixel + (item - chunk * n_pixels);
-    it.base = pixel_base(cam, (int)(pixel % (uint32_t)cam.width), (int)(pixel / (uint32_t)cam.width));
+    const uint32_t y = fast_div(pixel, P.by_width), x = pixel - y * (uint32_t)cam.width;
+    it.base = pixel_base(cam, (int)x, (int)y);
     const uint32_t s = first_sample + chunk * chunk_len, last = first_sample + spp;
     it.left = (s + chunk_len < last ? s + chunk_len : last) - s;
     it.key_term = s * RNG_STEP;
@@ -608,7 +624,7 @@ k_render_mega(RenderParams P)
             const uint32_t got = pool_take(pool, want, P.queue_head, P.n_items, P.pool_batch);
             if (want) {
                 if (got == NO_ITEM) break;      // queue empty: this lane retires
-                item_open(it, got, P.cam, P.n_pixels, P.first_pixel, P.first_sample, P.spp, P.chunk_len, P.seed_mix);
+                item_open(it, got, P);
             }
         }
         if (need_path) {
@@ -651,7 +667,7 @@ k_render_mega_tiled(RenderParams P)
             const uint32_t got = pool_take(pool, want, P.queue_head, P.n_items, P.pool_batch);
             if (want) {
                 if (got == NO_ITEM) alive = false;
-                else item_open(it, got, P.cam, P.n_pixels, P.first_pixel, P.first_sample, P.spp, P.chunk_len, P.seed_mix);
+                else item_open(it, got, P);
             }
         }
         if (__syncthreads_count(alive) == 0) break;             // workgroup-uniform
@@ -749,7 +765,7 @@ k_render_mega_bvh(RenderParams P)
                 const uint32_t got = pool_take(pool, want, P.queue_head, P.n_items, P.pool_batch);
                 if (want) {
                     if (got == NO_ITEM) alive = false;       // queue empty: this lane retires
-                    else item_open(it, got, P.cam, P.n_pixels, P.first_pixel, P.first_sample, P.spp, P.chunk_len, P.seed_mix);
+                    else item_open(it, got, P);
                 }
             }
             if (waits && alive) {
