@@ -292,6 +292,30 @@ def test_render_paths_match_oracle(ctx, pt, orc, name):
     assert cnt.tests == cnt.segments * len(pt.builtin_scene(name, w, h).surfaces)
 
 
+@pytest.mark.parametrize("w,h,spp", [(1, 1, 64), (1, 37, 16), (41, 1, 16), (2, 3, 32), (64, 2, 8), (127, 3, 8),
+                                      (128, 5, 8), (129, 5, 8), (256, 4, 4), (1021, 2, 2)])
+def test_render_at_awkward_image_sizes(ctx, pt, orc, w, h, spp):
+    """The render kernels find a work item's chunk of samples and its pixel's column and row by
+    multiplication and shift with constants of the launch (widths of one pixel, of a power of two,
+    one more, one less, a prime): every pixel must be the oracle's pixel, path-matched as in
+    test_render_paths_match_oracle, and the sample ranges of two launches must add up."""
+    sc = pt.builtin_scene("cornell_2", w, h)
+    acc, cnt = render(ctx, pt, sc, spp, seed=5)
+    oacc, ocnt = orc.render(orc.builtin_scene("cornell_2", w, h), spp, seed=5, threads=4)
+    assert acc.shape == oacc.shape == (h, w, 3)
+    close = np.isclose(acc, oacc, rtol=2e-3, atol=2e-3 * spp).all(axis=2)
+    # (a few pixels only: the share that matches is held per image above, here per pixel count)
+    assert close.sum() >= close.size - max(1, int(0.05 * close.size)), "%d of %d pixels differ" % ((~close).sum(), close.size)
+    assert abs(cnt.segments - ocnt.segments) <= max(4, 0.02 * ocnt.segments)
+    # the same image from two launches over halves of the samples (other chunk boundaries)
+    ctx.clear()
+    ctx.render(spp // 2, 0, 5, pt.MODE_MEGAKERNEL | pt.NUM_EXACT)
+    ctx.render(spp - spp // 2, spp // 2, 5, pt.MODE_MEGAKERNEL | pt.NUM_EXACT)
+    halves, total = ctx.read_accum()
+    assert total == spp
+    assert np.allclose(halves, acc, rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("cap", [1, 3, 7])
 def test_path_length_cap_matches_oracle(ctx, pt, orc, cap):
     """pt_set_max_depth against the oracle's path cap: paths end after the same segment, so
