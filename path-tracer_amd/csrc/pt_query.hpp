@@ -36,8 +36,9 @@ PT_DEV int uniform_kind(float w)
 
 // closest_intersection for N rays of one lane, EXACT policy: the error-band filter of
 // scan_surface per ray, the rare undecided ray re-evaluated by closest_direct from the
-// records in global memory (geom).
-template <int N>
+// records in global memory (geom).  WAVE_SKIP: scan_surface's wave-level early-outs, for callers
+// whose k-th rays are neighbours across the wave (camera rays).
+template <int N, bool WAVE_SKIP = false>
 PT_DEV void closest_hits_exact(const float *recs, cfloat_p geom, int n_surfaces, const V3 (&o)[N], const V3 (&d)[N],
                                Hit (&h)[N], unsigned long long *redo_count = nullptr)
 {
@@ -52,11 +53,11 @@ PT_DEV void closest_hits_exact(const float *recs, cfloat_p geom, int n_surfaces,
         if (rec.kind == GEOM_TRIANGLE) {                         // wave-uniform
             rec.q2 = p[2];
 #pragma unroll
-            for (int k = 0; k < N; k++) scan_surface<false, false, GEOM_TRIANGLE, true>(st[k], i, rec, o[k], d[k]);
+            for (int k = 0; k < N; k++) scan_surface<false, WAVE_SKIP, GEOM_TRIANGLE, true>(st[k], i, rec, o[k], d[k]);
         } else {
             rec.q2 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int k = 0; k < N; k++) scan_surface<false, false, GEOM_SPHERE, true>(st[k], i, rec, o[k], d[k]);
+            for (int k = 0; k < N; k++) scan_surface<false, WAVE_SKIP, GEOM_SPHERE, true>(st[k], i, rec, o[k], d[k]);
         }
     }
 #pragma unroll
@@ -73,7 +74,7 @@ PT_DEV void closest_hits_exact(const float *recs, cfloat_p geom, int n_surfaces,
 }
 
 // The same for the FAST policy: lean records, lean_triangle / lean_sphere.
-template <int N>
+template <int N, bool WAVE_SKIP = false>
 PT_DEV void closest_hits_lean(const float *recs, int n_surfaces, const V3 (&o)[N], const V3 (&d)[N], Hit (&h)[N])
 {
     LeanBest best[N];
@@ -96,7 +97,7 @@ PT_DEV void closest_hits_lean(const float *recs, int n_surfaces, const V3 (&o)[N
         } else {
             r.q2 = r.q3 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int k = 0; k < N; k++) lean_sphere<false>(best[k], i, r, ray[k]);
+            for (int k = 0; k < N; k++) lean_sphere<WAVE_SKIP>(best[k], i, r, ray[k]);
         }
     }
 #pragma unroll
@@ -108,11 +109,11 @@ PT_DEV void closest_hits_lean(const float *recs, int n_surfaces, const V3 (&o)[N
     }
 }
 
-template <bool FAST, int N>
+template <bool FAST, int N, bool WAVE_SKIP = false>
 PT_DEV void closest_hits(const float *recs, const float *geom, int n_surfaces, const V3 (&o)[N], const V3 (&d)[N], Hit (&h)[N])
 {
-    if constexpr (FAST) closest_hits_lean<N>(recs, n_surfaces, o, d, h);
-    else closest_hits_exact<N>(recs, as_constant(geom), n_surfaces, o, d, h);
+    if constexpr (FAST) closest_hits_lean<N, WAVE_SKIP>(recs, n_surfaces, o, d, h);
+    else closest_hits_exact<N, WAVE_SKIP>(recs, as_constant(geom), n_surfaces, o, d, h);
 }
 
 }  // namespace ptd

@@ -44,6 +44,9 @@ static bool write_ppm(const std::string &path, int width, int height, const std:
 
 int main(int argc, char *argv[])
 {
+    // the renderers behind trace_rays and the gateways are released when main ends, while the HIP
+    // runtime is still whole (pt::shutdown)
+    struct Release { ~Release() { pt::shutdown(); } } release_at_end;
     std::string scene_name = "orange_plane", scene_file, out;   // the reference's default scene (src/main.cpp:311)
     int width = 356, height = 200, passes = 100, batch = 0, gpus = 0;
     bool fast = false, viewer = false, log_images = false, exit_at_target = false;

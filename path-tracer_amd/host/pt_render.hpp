@@ -13,6 +13,8 @@
 
 #include <cstdint>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <typeinfo>
@@ -250,10 +252,39 @@ class Renderer {
     }
 };
 
+// The renderers behind the free functions below (trace_rays, the Material and Surface gateways):
+// made on first use, released by pt::shutdown().  They are deliberately NOT objects with static
+// storage: such an object's destructor would call into the HIP runtime while the process is being
+// torn down, in an order relative to the runtime's own teardown that nothing guarantees (a
+// segmentation fault at exit, one run in some tens, is what that looks like).  A program that
+// never calls shutdown() leaves the contexts to the operating system.
+struct SharedRenderers {
+    std::mutex lock;
+    std::unique_ptr<Renderer> render, probe;
+};
+
+inline SharedRenderers &shared_renderers()
+{
+    static SharedRenderers *shared = new SharedRenderers;     // never deleted, see above
+    return *shared;
+}
+
 inline Renderer &default_renderer()
 {
-    static Renderer r(0);
-    return r;
+    SharedRenderers &s = shared_renderers();
+    std::lock_guard<std::mutex> hold(s.lock);
+    if (!s.render) s.render.reset(new Renderer(0));
+    return *s.render;
+}
+
+// Releases the renderers of the free functions (their device memory, streams and events); they
+// are made again on the next use.  Call it before main returns, not from a static destructor.
+inline void shutdown()
+{
+    SharedRenderers &s = shared_renderers();
+    std::lock_guard<std::mutex> hold(s.lock);
+    s.render.reset();
+    s.probe.reset();
 }
 
 // ---- single-query gateways used by Material and Surface methods ----
@@ -286,7 +317,14 @@ inline bool gpu_intersect(const pt_surface &surface, vec3 start, vec3 dir, vec3 
 {
     // A context of its own, so that one-surface queries never disturb the scene
     // loaded in the default renderer.
-    static Renderer probe(0);
+    Renderer *probe_ptr;
+    {
+        SharedRenderers &shared = shared_renderers();
+        std::lock_guard<std::mutex> hold(shared.lock);
+        if (!shared.probe) shared.probe.reset(new Renderer(0));
+        probe_ptr = shared.probe.get();
+    }
+    Renderer &probe = *probe_ptr;
     pt_surface s = surface;
     s.material = 0;
     pt_material m{};
