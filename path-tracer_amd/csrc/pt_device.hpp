@@ -561,7 +561,10 @@ PT_DEV void scan_begin(Scan &st, V3 d)
 // lane of the wave finds nearly every surface closer), 3 % slower on 16 surfaces, and 7-9 % faster
 // in the closest-hit queries with several rays per lane, where the compiler otherwise turns every
 // ray's update into a branch with register copies of its own.
-template <bool FAST, bool WAVE_SKIP = false, int KIND = -1, bool SELECT_UPDATE = false>
+// PRUNE (EXACT, with WAVE_SKIP): ask the wave, once a triangle's t is known, whether any lane can
+// still find it closer than the candidate it has; for callers whose rays are neighbours across the
+// wave (camera rays), where whole waves are past most surfaces after the first few.
+template <bool FAST, bool WAVE_SKIP = false, int KIND = -1, bool SELECT_UPDATE = false, bool PRUNE = false>
 PT_DEV void scan_surface(Scan &st, int i, const GeomRec &rec, V3 o, V3 d)
 {
     // Decisions are kept as wave masks (ballots of single comparisons, combined with
@@ -583,6 +586,16 @@ PT_DEV void scan_surface(Scan &st, int i, const GeomRec &rec, V3 o, V3 d)
         const float inv = __builtin_amdgcn_rcpf(q.det_a);
         const float u = q.du * inv;
         const Mask det_bad = PT_B(__builtin_fabsf(q.det_a) <= EPS_F);      // false for a NaN, as in the reference
+        if constexpr (PRUNE && !FAST) {
+            // Every lane either surely without a hit on t alone (or parallel), or with a candidate
+            // that this triangle, hit or not, is surely no closer than: nothing can change, not the
+            // candidate and not what is known for sure (a surface that cannot win need not be
+            // decided).  A NaN anywhere compares false: that lane keeps the wave here.
+            const float t_early = q.dt * inv;
+            const float lo_early = (t_early * len_d) * (1.0f - TRI_DIST_ERR);
+            const Mask past = or_lt<f32_bits(BAND_T_REJ)>(det_bad, t_early) | PT_B(lo_early >= best.hi);
+            if ((PT_B(true) & ~past) == 0) return;
+        }
         if constexpr (WAVE_SKIP) {
             // every lane surely outside on u alone (or parallel): v and t need not be formed
             const Mask out_on_u = or_gt<f32_bits(BAND_ONE_REJ)>(or_lt<f32_bits(BAND_LO_REJ)>(det_bad, u), u);
@@ -823,7 +836,9 @@ PT_DEV float lean_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0,
 // this code (the closest-hit queries) the packed form is 12 % faster; in the render kernels, whose
 // waves are spread over scan, shading and path set-up, other waves' plain instructions already
 // fill the slots behind a scalar operand, and the packed form is 3 % slower.
-template <bool WAVE_SKIP, bool PACKED>
+// PRUNE: ask the wave, once t is known, whether any lane can still be hit closer than what it has
+// (for callers whose rays are neighbours across the wave: camera rays).
+template <bool WAVE_SKIP, bool PACKED, bool PRUNE = false>
 PT_DEV void lean_triangle(LeanBest &best, int i, const LeanRec &r, const LeanRay &ray)
 {
     float den, num, t;
@@ -855,6 +870,12 @@ PT_DEV void lean_triangle(LeanBest &best, int i, const LeanRec &r, const LeanRay
         const float px = __builtin_fmaf(t, dx, ox), py = __builtin_fmaf(t, dy, oy), pz = __builtin_fmaf(t, dz, oz);
         uv.x = __builtin_fmaf(r.q2.z, pz, __builtin_fmaf(r.q2.x, py, __builtin_fmaf(r.q1.z, px, r.q3.z)));
         uv.y = __builtin_fmaf(r.q2.w, pz, __builtin_fmaf(r.q2.y, py, __builtin_fmaf(r.q1.w, px, r.q3.w)));
+    }
+    if constexpr (PRUNE) {
+        // no lane of the wave can still be hit closer than what it has (t behind the ray's start, or
+        // the plane farther than the lane's best hit; half of eps: never stricter than the margin
+        // below): the hit point and its coordinates need not be formed
+        if (!__any(t > 0.5f * EPS_F && t * ray.len_d < best.dist)) return;
     }
     // the margin of the comment above, less eps throughout: min(u, v, 1 - eps - (u + v), t - 2 eps,
     // |n.d| - (eps / |N| + eps)) > -eps.  (v_min3 drops a NaN operand: 0 * (u + v) carries a NaN

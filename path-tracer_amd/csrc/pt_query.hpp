@@ -53,7 +53,7 @@ PT_DEV void closest_hits_exact(const float *recs, cfloat_p geom, int n_surfaces,
         if (rec.kind == GEOM_TRIANGLE) {                         // wave-uniform
             rec.q2 = p[2];
 #pragma unroll
-            for (int k = 0; k < N; k++) scan_surface<false, WAVE_SKIP, GEOM_TRIANGLE, true>(st[k], i, rec, o[k], d[k]);
+            for (int k = 0; k < N; k++) scan_surface<false, WAVE_SKIP, GEOM_TRIANGLE, true, WAVE_SKIP>(st[k], i, rec, o[k], d[k]);
         } else {
             rec.q2 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -93,7 +93,7 @@ PT_DEV void closest_hits_lean(const float *recs, int n_surfaces, const V3 (&o)[N
         if (r.kind == GEOM_TRIANGLE) {                           // wave-uniform
             r.q2 = p[2]; r.q3 = p[3];
 #pragma unroll
-            for (int k = 0; k < N; k++) lean_triangle<false, false>(best[k], i, r, ray[k]);
+            for (int k = 0; k < N; k++) lean_triangle<false, false, WAVE_SKIP>(best[k], i, r, ray[k]);
         } else {
             r.q2 = r.q3 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
