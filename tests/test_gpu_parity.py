@@ -152,6 +152,49 @@ def test_query_kernels_with_several_rays_per_lane(ctx, pt, orc, per_lane, monkey
                 assert np.array_equal(a, b[:m])
 
 
+@pytest.mark.parametrize("name", SCENES)
+def test_camera_ray_queries_with_wave_level_early_outs_800(ctx, pt, golden, name, monkeypatch):
+    """The camera-ray query with several rays per lane asks the whole wave before it goes on with
+    a surface (every lane outside on u, past it on t, or holding a closer candidate): the form
+    large queries take by themselves, forced here at 800 x 800 on every built-in scene.  EXACT bit
+    for bit the golden indices and distances; FAST as the one-ray FAST kernel is held."""
+    g = golden("primary_hits_800.npz")
+    want_idx, want_dist = g[name + "_idx"].astype(np.int32), g[name + "_dist"]
+    load(ctx, pt.builtin_scene(name, 800, 800))
+    for per_lane in (2, 4, 8):
+        monkeypatch.setenv("PT_QUERY_RAYS", str(per_lane))
+        idx, dist = ctx.primary_hits()
+        # (the golden file holds every index and every eighth distance each way)
+        assert np.array_equal(idx, want_idx) and np.array_equal(dist[::8, ::8], want_dist), (name, per_lane)
+        fidx, fdist = ctx.primary_hits(pt.NUM_FAST)
+        assert (fidx != want_idx).sum() <= 2, (name, per_lane)
+        same = ((fidx == want_idx) & (want_idx >= 0))[::8, ::8]
+        assert np.allclose(fdist[::8, ::8][same], want_dist[same], rtol=3e-4), (name, per_lane)
+
+
+def test_camera_ray_queries_from_random_poses(ctx, pt, orc, monkeypatch):
+    """The same form from cameras it was not tuned on: poses inside and outside the Cornell box,
+    looking anywhere (whole waves then miss everything, or start behind surfaces, or look along a
+    wall), against the oracle's primary hits bit for bit."""
+    monkeypatch.setenv("PT_QUERY_RAYS", "4")
+    rng = np.random.default_rng(77)
+    for name in ("cornell_2", "cornell", "test"):
+        sc = pt.builtin_scene(name, 192, 128)
+        osc = orc.builtin_scene(name, 192, 128)
+        load(ctx, sc)
+        for trial in range(12):
+            pos = rng.uniform(-3.0, 3.0, 3).astype(np.float32)
+            if trial % 3 == 0:
+                pos = (rng.uniform(-0.9, 0.9, 3)).astype(np.float32)       # inside the box
+            cam = orc.camera_init(pos, float(rng.uniform(-1.5, 1.5)), float(rng.uniform(0, 6.28)),
+                                  float(rng.uniform(40, 400)), 1, 192, 128)
+            osc.camera[:] = cam
+            ctx.set_camera(cam)
+            idx, dist = ctx.primary_hits()
+            oidx, odist = orc.primary_hits(osc)
+            assert np.array_equal(idx, oidx) and np.array_equal(dist, odist), (name, trial)
+
+
 def test_intersect_edge_cases(ctx, pt, orc):
     """Coincident surfaces (lowest index wins), grazing and degenerate rays, rays
     parallel to a triangle, a ray starting inside a sphere, an empty batch."""
