@@ -457,7 +457,8 @@ int with_variant(bool fast, int kind, F &&f)
 // the one-ray kernels.  Measured on 16.8 M camera rays of cornell_2, ms with one ray per lane
 // through the scalar cache / 2 / 4 / 8 rays per lane: FAST 0.115 / 0.103 / 0.097 / 0.094; EXACT
 // 0.189 / 0.186 / 0.176 / 0.186 (124 registers at 8), and 0.350 / 0.340 / 0.320 / 0.343 on the 16
-// surfaces of cornell.  Scenes with a hierarchy, scenes whose records do not fit the kernels' LDS
+// surfaces of cornell (before the camera-ray kernel's wave-level early-outs, which the N-ray forms
+// alone have: with them EXACT 0.147 / 0.138 at 2 / 4, FAST 0.070 at 8).  Scenes with a hierarchy, scenes whose records do not fit the kernels' LDS
 // copy, and the LDS-tiled scan keep the one-ray kernels.  More rays per lane mean fewer
 // workgroups, so small queries take fewer.  PT_QUERY_RAYS (0, 1, 2, 4, 8) overrides the choice,
 // for either policy: for measurements and for the parity tests of every form.
